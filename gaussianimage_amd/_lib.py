@@ -1,0 +1,99 @@
+"""ctypes binding of ``csrc/libgi2d.so`` (the C ABI declared in ``include/gi2d.h``).
+
+The library is the only backend of this package: there is no CPU or PyTorch
+fallback.  A missing or unloadable library raises at import of this module.
+"""
+import ctypes
+import os
+
+# PyTorch-ROCm carries its own copy of the HIP runtime (same SONAME as /opt/rocm's).  It must
+# be the one already mapped when libgi2d.so is loaded, or the process ends up with two HIP
+# runtimes and torch's device pointers and streams mean nothing to this library.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgi2d.so")
+
+GI2D_OK = 0
+GI2D_E_INVALID = -1
+GI2D_E_STATE = -2
+GI2D_E_CAPACITY = -3
+GI2D_E_PREV_OVERFLOW = -4
+
+BIN_SYNC = 1
+BIN_COUNTED = 2
+BIN_NOGROW = 4
+
+OPT_CULL = 1
+
+BLOCK = 16
+
+
+class Conv(ctypes.Structure):
+    """Mirror of ``gi2d_conv``."""
+    _fields_ = [("pixel_offset", ctypes.c_float), ("center_bias", ctypes.c_float),
+                ("alpha_cap", ctypes.c_float), ("alpha_min", ctypes.c_float),
+                ("bg_weight", ctypes.c_float)]
+
+
+_vp, _i, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+_convp = ctypes.POINTER(Conv)
+
+# name -> (restype, argtypes); every symbol that include/gi2d.h declares
+SIGNATURES = {
+    "gi2d_version": (_i, []),
+    "gi2d_error_string": (ctypes.c_char_p, [_i]),
+    "gi2d_default_conv": (None, [_convp]),
+    "gi2d_workspace_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "gi2d_workspace_destroy": (_i, [_vp]),
+    "gi2d_workspace_reserve": (_i, [_vp, _i64, _i]),
+    "gi2d_workspace_set_option": (_i, [_vp, _i, _i]),
+    "gi2d_workspace_info": (_i, [_vp, ctypes.POINTER(_i64)]),
+    "gi2d_project_cholesky_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _convp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp, _vp]),
+    "gi2d_project_rs_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _convp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp]),
+    "gi2d_project_cholesky_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gi2d_project_rs_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gi2d_bin_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "gi2d_copy_bins": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "gi2d_rasterize_sum_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp]),
+    "gi2d_rasterize_sum_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m gaussianimage_amd.build` "
+            "(hipcc, gfx950). This package has no fallback backend.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class Gi2dError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = lib.gi2d_error_string(status).decode()
+        super().__init__(f"{where}: {msg} (status {status})")
+
+
+def check(status, where):
+    if status != GI2D_OK:
+        raise Gi2dError(status, where)
+
+
+def default_conv(**over):
+    c = Conv()
+    lib.gi2d_default_conv(ctypes.byref(c))
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c

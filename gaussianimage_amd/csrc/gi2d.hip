@@ -1,0 +1,1105 @@
+// gi2d.hip -- MI355X (gfx950, wave64) kernels and C ABI of the accumulated-summation
+// 2D Gaussian rasterizer: projection, tile binning, rasterize_sum forward/backward.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see build.py).
+// -ffp-contract=off is part of the contract: the projection's integer outputs (radii, tile
+// boxes) must not depend on the compiler's choice of fused multiply-adds.  Where a fused
+// multiply-add is wanted in a hot loop it is written explicitly with __builtin_fmaf.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include <new>
+
+#include "../../include/gi2d.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+
+// status words written by the scan kernel and read by everything after it
+struct DevStatus {
+    int overflow;        // 1: the lists do not fit, later kernels skip their work
+    int pad;
+    long long total;     // number of (tile, Gaussian) intersections
+};
+
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (!(v == v)) return 0;
+    v = fminf(fmaxf(v, -2147483520.0f), 2147483520.0f);
+    return (int)v;
+}
+
+// Conic (inverse covariance) and integer 3-sigma radius; false = early-out.
+__device__ __forceinline__ bool cov_to_conic_radius(float sxx, float sxy, float syy, float &ca,
+                                                    float &cb, float &cc, float &radius)
+{
+    float det = sxx * syy - sxy * sxy;
+    if (det == 0.0f || !(fabsf(det) <= 3.0e38f)) return false;
+    float inv_det = 1.0f / det;
+    ca = syy * inv_det;
+    cb = -sxy * inv_det;
+    cc = sxx * inv_det;
+    float b = 0.5f * (sxx + syy);
+    float disc = fmaxf(0.1f, b * b - det);
+    float s = sqrtf(disc);
+    float v1 = b + s;
+    float v2 = b - s;
+    float r = ceilf(3.0f * sqrtf(fmaxf(v1, v2)));
+    if (!(r <= 3.0e38f)) return false;
+    radius = r;
+    return true;
+}
+
+struct TileBox {
+    int x0, x1, y0, y1;  // [x0,x1) x [y0,y1)
+};
+
+__device__ __forceinline__ TileBox tile_box(float cx, float cy, float radius, int tiles_x,
+                                            int tiles_y)
+{
+    float tcx = cx / (float)GI2D_BLOCK, tcy = cy / (float)GI2D_BLOCK;
+    float tr = radius / (float)GI2D_BLOCK;
+    TileBox b;
+    b.x0 = min(max(0, f2i_sat(tcx - tr)), tiles_x);
+    b.x1 = min(max(0, f2i_sat(tcx + tr + 1.0f)), tiles_x);
+    b.y0 = min(max(0, f2i_sat(tcy - tr)), tiles_y);
+    b.y1 = min(max(0, f2i_sat(tcy + tr + 1.0f)), tiles_y);
+    return b;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over the 4 lanes of a quad, result in every lane of the quad
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v = v + dpp_mov<0xB1>(v);  // quad_perm:[1,0,3,2]
+    v = v + dpp_mov<0x4E>(v);  // quad_perm:[2,3,0,1]
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// projection (one lane per Gaussian)
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void project_tail(int g, float mx, float my, float sxx, float sxy,
+                                             float syy, int H, int W, int tiles_x, int tiles_y,
+                                             float center_bias, float *xys, float *depths,
+                                             int *radii, float *conics, int *num_tiles_hit,
+                                             int *tile_count)
+{
+    float ca = 0.f, cb = 0.f, cc = 0.f, radius = 0.f, cx = 0.f, cy = 0.f;
+    int irad = 0, area = 0;
+    TileBox box = {0, 0, 0, 0};
+    if (cov_to_conic_radius(sxx, sxy, syy, ca, cb, cc, radius)) {
+        cx = 0.5f * (float)W * mx + 0.5f * (float)W + center_bias;
+        cy = 0.5f * (float)H * my + 0.5f * (float)H + center_bias;
+        irad = f2i_sat(radius);
+        box = tile_box(cx, cy, radius, tiles_x, tiles_y);
+        area = (box.x1 - box.x0) * (box.y1 - box.y0);
+        if (area < 0) area = 0;
+    } else {
+        ca = cb = cc = 0.f;
+    }
+    xys[2 * g] = cx;
+    xys[2 * g + 1] = cy;
+    depths[g] = 0.0f;
+    radii[g] = irad;
+    conics[3 * g] = ca;
+    conics[3 * g + 1] = cb;
+    conics[3 * g + 2] = cc;
+    num_tiles_hit[g] = area;
+    if (tile_count != nullptr && irad > 0 && area > 0) {
+        for (int ty = box.y0; ty < box.y1; ++ty)
+            for (int tx = box.x0; tx < box.x1; ++tx) atomicAdd(&tile_count[ty * tiles_x + tx], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
+    const float *__restrict__ means, const float *__restrict__ L, int N, int H, int W, int tiles_x,
+    int tiles_y, float center_bias, float *__restrict__ xys, float *__restrict__ depths,
+    int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
+    int *tile_count)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float l11 = L[3 * g], l21 = L[3 * g + 1], l22 = L[3 * g + 2];
+    float sxx = l11 * l11;
+    float sxy = l11 * l21;
+    float syy = l21 * l21 + l22 * l22;
+    project_tail(g, means[2 * g], means[2 * g + 1], sxx, sxy, syy, H, W, tiles_x, tiles_y,
+                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count);
+}
+
+__global__ __launch_bounds__(256) void project_rs_fwd_kernel(
+    const float *__restrict__ means, const float *__restrict__ scales,
+    const float *__restrict__ rot, int N, int H, int W, int tiles_x, int tiles_y,
+    float center_bias, float *__restrict__ xys, float *__restrict__ depths,
+    int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
+    int *tile_count)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float s, c;
+    sincosf(rot[g], &s, &c);
+    float s1 = scales[2 * g], s2 = scales[2 * g + 1];
+    float q1 = s1 * s1, q2 = s2 * s2;
+    float sxx = c * c * q1 + s * s * q2;
+    float sxy = c * s * (q1 - q2);
+    float syy = s * s * q1 + c * c * q2;
+    project_tail(g, means[2 * g], means[2 * g + 1], sxx, sxy, syy, H, W, tiles_x, tiles_y,
+                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count);
+}
+
+// dL/dSigma from dL/dconic: with C = Sigma^-1 and V = [[va, vb/2],[vb/2, vc]], G = -C V C;
+// returned as (gxx, gxy, gyy), gxy being the derivative w.r.t. the single parameter sxy.
+__device__ __forceinline__ void conic_grad_to_cov_grad(float a, float b, float c, float va,
+                                                       float vb2, float vc, float &gxx, float &gxy,
+                                                       float &gyy)
+{
+    float vb = 0.5f * vb2;
+    float m00 = a * va + b * vb, m01 = a * vb + b * vc;
+    float m10 = b * va + c * vb, m11 = b * vb + c * vc;
+    gxx = -(m00 * a + m01 * b);
+    float g01 = -(m00 * b + m01 * c);
+    float g10 = -(m10 * a + m11 * b);
+    gyy = -(m10 * b + m11 * c);
+    gxy = g01 + g10;
+}
+
+__global__ __launch_bounds__(256) void project_cholesky_bwd_kernel(
+    const float *__restrict__ L, int N, int H, int W, const float *__restrict__ v_xy,
+    const float *__restrict__ v_conic, float *__restrict__ v_means, float *__restrict__ v_L)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float l11 = L[3 * g], l21 = L[3 * g + 1], l22 = L[3 * g + 2];
+    float sxx = l11 * l11, sxy = l11 * l21, syy = l21 * l21 + l22 * l22;
+    float a, b, c, radius;
+    float vm0 = 0.f, vm1 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (cov_to_conic_radius(sxx, sxy, syy, a, b, c, radius)) {
+        float gxx, gxy, gyy;
+        conic_grad_to_cov_grad(a, b, c, v_conic[3 * g], v_conic[3 * g + 1], v_conic[3 * g + 2],
+                               gxx, gxy, gyy);
+        vm0 = 0.5f * (float)W * v_xy[2 * g];
+        vm1 = 0.5f * (float)H * v_xy[2 * g + 1];
+        o0 = 2.0f * l11 * gxx + l21 * gxy;
+        o1 = l11 * gxy + 2.0f * l21 * gyy;
+        o2 = 2.0f * l22 * gyy;
+    }
+    v_means[2 * g] = vm0;
+    v_means[2 * g + 1] = vm1;
+    v_L[3 * g] = o0;
+    v_L[3 * g + 1] = o1;
+    v_L[3 * g + 2] = o2;
+}
+
+__global__ __launch_bounds__(256) void project_rs_bwd_kernel(
+    const float *__restrict__ scales, const float *__restrict__ rot, int N, int H, int W,
+    const float *__restrict__ v_xy, const float *__restrict__ v_conic,
+    float *__restrict__ v_means, float *__restrict__ v_scales, float *__restrict__ v_rot)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float s, c;
+    sincosf(rot[g], &s, &c);
+    float s1 = scales[2 * g], s2 = scales[2 * g + 1];
+    float q1 = s1 * s1, q2 = s2 * s2;
+    float sxx = c * c * q1 + s * s * q2;
+    float sxy = c * s * (q1 - q2);
+    float syy = s * s * q1 + c * c * q2;
+    float a, b, cc, radius;
+    float vm0 = 0.f, vm1 = 0.f, vs0 = 0.f, vs1 = 0.f, vr = 0.f;
+    if (cov_to_conic_radius(sxx, sxy, syy, a, b, cc, radius)) {
+        float gxx, gxy, gyy;
+        conic_grad_to_cov_grad(a, b, cc, v_conic[3 * g], v_conic[3 * g + 1], v_conic[3 * g + 2],
+                               gxx, gxy, gyy);
+        vm0 = 0.5f * (float)W * v_xy[2 * g];
+        vm1 = 0.5f * (float)H * v_xy[2 * g + 1];
+        float gq1 = gxx * c * c + gxy * c * s + gyy * s * s;
+        float gq2 = gxx * s * s - gxy * c * s + gyy * c * c;
+        vs0 = 2.0f * s1 * gq1;
+        vs1 = 2.0f * s2 * gq2;
+        float dq = q1 - q2;
+        vr = dq * (-2.0f * c * s * gxx + (c * c - s * s) * gxy + 2.0f * c * s * gyy);
+    }
+    v_means[2 * g] = vm0;
+    v_means[2 * g + 1] = vm1;
+    v_scales[2 * g] = vs0;
+    v_scales[2 * g + 1] = vs1;
+    v_rot[g] = vr;
+}
+
+// ------------------------------------------------------------------------------------------
+// tile binning: count -> scan -> fill -> per-tile sort
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void zero_ints_kernel(int *p, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void count_tiles_kernel(const float *__restrict__ xys,
+                                                           const int *__restrict__ radii, int N,
+                                                           int tiles_x, int tiles_y,
+                                                           int *tile_count)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    int r = radii[g];
+    if (r <= 0) return;
+    TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
+    for (int ty = box.y0; ty < box.y1; ++ty)
+        for (int tx = box.x0; tx < box.x1; ++tx) atomicAdd(&tile_count[ty * tiles_x + tx], 1);
+}
+
+// One workgroup: exclusive scan of the per-tile counts into tile_offsets[T+1]; leaves the
+// counters at zero so that the fill kernel can use them as per-tile cursors.
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(int *tile_count, int *tile_offsets, int T,
+                                                           long long ids_cap, DevStatus *status,
+                                                           volatile long long *h_status,
+                                                           long long generation)
+{
+    __shared__ long long wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (T + 1023) / 1024;
+    const int b = min(T, tid * chunk), e = min(T, b + chunk);
+    long long s = 0;
+    for (int i = b; i < e; ++i) s += tile_count[i];
+    long long inc = s;
+    for (int d = 1; d < 64; d <<= 1) {
+        long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    long long wbase = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        long long v = wave_tot[w];
+        if (w < wave) wbase += v;
+        total += v;
+    }
+    long long run = wbase + inc - s;
+    for (int i = b; i < e; ++i) {
+        int c = tile_count[i];
+        tile_offsets[i] = (int)(run < (long long)INT_MAX ? run : (long long)INT_MAX);
+        run += c;
+        tile_count[i] = 0;
+    }
+    if (tid == 0) {
+        bool over = total > ids_cap || total >= (long long)INT_MAX;
+        tile_offsets[T] = (int)(total < (long long)INT_MAX ? total : (long long)INT_MAX);
+        status->overflow = over ? 1 : 0;
+        status->total = total;
+        h_status[0] = total;
+        h_status[1] = generation;
+        if (over) h_status[2] = generation;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_tiles_kernel(const float *__restrict__ xys,
+                                                          const int *__restrict__ radii, int N,
+                                                          int tiles_x, int tiles_y,
+                                                          const int *__restrict__ tile_offsets,
+                                                          int *tile_cursor, int *ids,
+                                                          const DevStatus *status)
+{
+    if (status->overflow) return;
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    int r = radii[g];
+    if (r <= 0) return;
+    TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
+    for (int ty = box.y0; ty < box.y1; ++ty)
+        for (int tx = box.x0; tx < box.x1; ++tx) {
+            int t = ty * tiles_x + tx;
+            int pos = atomicAdd(&tile_cursor[t], 1);
+            ids[tile_offsets[t] + pos] = g;
+        }
+}
+
+// ascending in-place bitonic network; elements past n are a virtual +infinity
+template <typename P>
+__device__ __forceinline__ void bitonic_sort(P a, int n, int lane, int nthreads)
+{
+    int npow = 1;
+    while (npow < n) npow <<= 1;
+    const int half = npow >> 1;
+    for (int k = 2; k <= npow; k <<= 1) {
+        const int hk = k >> 1;
+        for (int i = lane; i < half; i += nthreads) {
+            int blk = i / hk, off = i - blk * hk;
+            int lo = blk * k + off, hi = blk * k + k - 1 - off;
+            if (hi < n) {
+                int x = a[lo], y = a[hi];
+                if (x > y) {
+                    a[lo] = y;
+                    a[hi] = x;
+                }
+            }
+        }
+        __syncthreads();
+        for (int j = hk >> 1; j >= 1; j >>= 1) {
+            for (int i = lane; i < half; i += nthreads) {
+                int lo = 2 * j * (i / j) + (i % j), hi = lo + j;
+                if (hi < n) {
+                    int x = a[lo], y = a[hi];
+                    if (x > y) {
+                        a[lo] = y;
+                        a[hi] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+#define SORT_LDS_MAX 4096
+
+// One wave per tile: puts the tile's Gaussian ids in ascending order (the fill order depends
+// on atomic arrival) and returns the tile's cursor to zero for the next binning.
+__global__ __launch_bounds__(WAVE) void sort_tiles_kernel(const int *__restrict__ tile_offsets,
+                                                          int *ids, int *tile_cursor,
+                                                          const DevStatus *status)
+{
+    __shared__ int s_ids[SORT_LDS_MAX];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (lane == 0) tile_cursor[t] = 0;
+    if (status->overflow) return;
+    const int beg = tile_offsets[t], n = tile_offsets[t + 1] - beg;
+    if (n <= 1) return;
+    if (n <= WAVE) {
+        int v = lane < n ? ids[beg + lane] : INT_MAX;
+        int rank = 0;
+        const int nu = __builtin_amdgcn_readfirstlane(n);
+        for (int k = 0; k < nu; ++k) rank += (__builtin_amdgcn_readlane(v, k) < v) ? 1 : 0;
+        if (lane < n) ids[beg + rank] = v;
+    } else if (n <= SORT_LDS_MAX) {
+        for (int i = lane; i < n; i += WAVE) s_ids[i] = ids[beg + i];
+        __syncthreads();
+        bitonic_sort(s_ids, n, lane, WAVE);
+        for (int i = lane; i < n; i += WAVE) ids[beg + i] = s_ids[i];
+    } else {
+        bitonic_sort(ids + beg, n, lane, WAVE);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rasterize_sum forward: one 16x16 workgroup per tile, one pixel per lane; the tile's
+// Gaussians are staged through LDS in batches of 256 and read back as broadcasts.
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
+    const int *__restrict__ tile_offsets, const int *__restrict__ ids,
+    const float *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacity, float bg0, float bg1,
+    float bg2, int H, int W, int tiles_x, gi2d_conv cv, const DevStatus *status,
+    float *__restrict__ out)
+{
+    __shared__ float4 s_a[256];  // gx, gy, conic a, conic b
+    __shared__ float4 s_b[256];  // conic c, opacity, colour r, colour g
+    __shared__ float s_c[256];   // colour b
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x;
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
+    const bool inside = (i < H) && (j < W);
+    const float px = (float)j + cv.pixel_offset, py = (float)i + cv.pixel_offset;
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (status->overflow) {
+        r = g = b = __builtin_nanf("");
+    } else {
+        const int beg = tile_offsets[t], end = tile_offsets[t + 1];
+        for (int base = beg; base < end; base += 256) {
+            const int n = min(256, end - base);
+            __syncthreads();
+            if (tid < n) {
+                int gid = ids[base + tid];
+                s_a[tid] = make_float4(xys[2 * gid], xys[2 * gid + 1], conics[3 * gid],
+                                       conics[3 * gid + 1]);
+                s_b[tid] = make_float4(conics[3 * gid + 2], opacity[gid], colors[3 * gid],
+                                       colors[3 * gid + 1]);
+                s_c[tid] = colors[3 * gid + 2];
+            }
+            __syncthreads();
+            for (int k = 0; k < n; ++k) {
+                const float4 A = s_a[k];
+                const float4 B = s_b[k];
+                const float cb = s_c[k];
+                const float dx = A.x - px, dy = A.y - py;
+                const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
+                const float e = __builtin_amdgcn_exp2f(-sigma * 1.4426950408889634f);
+                const float alpha = fminf(cv.alpha_cap, B.y * e);
+                const float w = (sigma < 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
+                r = r + B.z * w;
+                g = g + B.w * w;
+                b = b + cb * w;
+            }
+        }
+        r = r + cv.bg_weight * bg0;
+        g = g + cv.bg_weight * bg1;
+        b = b + cv.bg_weight * bg2;
+    }
+    if (inside) {
+        float *o = out + 3 * ((size_t)i * W + j);
+        o[0] = r;
+        o[1] = g;
+        o[2] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rasterize_sum backward.
+//
+// Pass 1 (one workgroup per tile): lane = (list entry, 4-row strip of the tile).  Each lane
+// walks only the pixels of its strip that lie inside the entry's support rectangle (the
+// bounding box of the ellipse alpha >= alpha_min), keeps the entry's nine partial sums in
+// registers, the four strips are added with two DPP steps, and the tile's sums are written to
+// the entry's own slot of a [slots][9] slab -- no cross-lane tree, no atomics.
+// Pass 2 (one lane per Gaussian): adds the Gaussian's slots in tile order; a slot is found by
+// binary search because tile lists are ascending in Gaussian id.
+// ------------------------------------------------------------------------------------------
+
+#define PART_STRIDE 9
+
+// Tile-local pixel range [lo,hi] (inclusive) whose sample coordinate o+l lies within h of c.
+__device__ __forceinline__ void axis_range(float c, float o, float h, int lim_lo, int lim_hi,
+                                           int &lo, int &hi)
+{
+    float flo = ceilf(c - o - h), fhi = floorf(c - o + h);
+    flo = fminf(fmaxf(flo, -1.0f), 32.0f);
+    fhi = fminf(fmaxf(fhi, -2.0f), 32.0f);
+    lo = max(lim_lo, (int)flo);
+    hi = min(lim_hi, (int)fhi);
+}
+
+__global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
+    const int *__restrict__ tile_offsets, const int *__restrict__ ids,
+    const float *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacity, int H, int W,
+    int tiles_x, gi2d_conv cv, int cull, const DevStatus *status,
+    const float *__restrict__ v_out, float *__restrict__ partials)
+{
+    __shared__ float s_v[3][256];
+    if (status->overflow) return;
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x;
+    const int beg = tile_offsets[t], end = tile_offsets[t + 1];
+    if (beg == end) return;
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    {
+        const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (i < H && j < W) {
+            const float *p = v_out + 3 * ((size_t)i * W + j);
+            v0 = p[0];
+            v1 = p[1];
+            v2 = p[2];
+        }
+        s_v[0][tid] = v0;
+        s_v[1][tid] = v1;
+        s_v[2][tid] = v2;
+    }
+    __syncthreads();
+    const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
+    const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
+    const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
+    const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
+    const int strip = tid & 3;
+    for (int base = beg; base < end; base += 64) {
+        const int e = base + (tid >> 2);
+        float acc[PART_STRIDE];
+#pragma unroll
+        for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
+        if (e < end) {
+            const int gid = ids[e];
+            const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
+            const float a = conics[3 * gid], b = conics[3 * gid + 1], c = conics[3 * gid + 2];
+            const float op = opacity[gid];
+            const float cr = colors[3 * gid], cg = colors[3 * gid + 1], cb = colors[3 * gid + 2];
+            int x0 = 0, x1 = x_hi, y0 = strip * 4, y1 = min(strip * 4 + 3, y_hi);
+            if (cull) {
+                // alpha >= alpha_min  <=>  sigma <= tau = ln(op/alpha_min); inside that ellipse
+                // |dx| <= sqrt(2 tau c/det), |dy| <= sqrt(2 tau a/det).  Trusted only for a
+                // well-conditioned positive-definite conic, padded against rounding.
+                const float det = a * c - b * b;
+                const float ratio = op / cv.alpha_min;
+                if (!(ratio >= 1.0f)) {
+                    x1 = -1;  // no pixel can reach alpha_min
+                } else if (a > 0.f && c > 0.f && det > 1.0e-3f * a * c && ratio < 3.0e38f) {
+                    const float tau = 1.001f * __logf(ratio) + 1.0e-3f;
+                    const float hx = 1.001f * sqrtf(2.0f * tau * c / det) + 1.0e-3f;
+                    const float hy = 1.001f * sqrtf(2.0f * tau * a / det) + 1.0e-3f;
+                    if (hx < 1.0e6f && hy < 1.0e6f) {
+                        axis_range(gx, ox, hx, 0, x_hi, x0, x1);
+                        axis_range(gy, oy, hy, y0, y1, y0, y1);
+                    }
+                }
+            }
+            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+            const int cnt = (w > 0 && h > 0) ? w * h : 0;
+            int x = x0, y = y0;
+            for (int k = 0; k < cnt; ++k) {
+                const float dx = gx - (ox + (float)x), dy = gy - (oy + (float)y);
+                const float sigma = 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
+                const float ex = __builtin_amdgcn_exp2f(-sigma * 1.4426950408889634f);
+                const float oe = op * ex;
+                const float alpha = fminf(cv.alpha_cap, oe);
+                if (!(sigma < 0.f || alpha < cv.alpha_min)) {
+                    const int p = y * GI2D_BLOCK + x;
+                    const float v0 = s_v[0][p], v1 = s_v[1][p], v2 = s_v[2][p];
+                    acc[5] += alpha * v0;
+                    acc[6] += alpha * v1;
+                    acc[7] += alpha * v2;
+                    if (!(oe > cv.alpha_cap)) {
+                        const float v_alpha = cr * v0 + cg * v1 + cb * v2;
+                        const float v_sigma = -oe * v_alpha;
+                        acc[8] += ex * v_alpha;
+                        acc[0] += v_sigma * (a * dx + b * dy);
+                        acc[1] += v_sigma * (b * dx + c * dy);
+                        acc[2] += v_sigma * (0.5f * dx * dx);
+                        acc[3] += v_sigma * (dx * dy);
+                        acc[4] += v_sigma * (0.5f * dy * dy);
+                    }
+                }
+                if (++x > x1) {
+                    x = x0;
+                    ++y;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PART_STRIDE; ++k) acc[k] = quad_sum(acc[k]);
+        if (e < end && strip == 0) {
+            float *dst = partials + (size_t)e * PART_STRIDE;
+#pragma unroll
+            for (int k = 0; k < PART_STRIDE; ++k) dst[k] = acc[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_grads_kernel(
+    const float *__restrict__ xys, const int *__restrict__ radii, int N, int tiles_x, int tiles_y,
+    const int *__restrict__ tile_offsets, const int *__restrict__ ids,
+    const float *__restrict__ partials, const DevStatus *status, float *__restrict__ v_xy,
+    float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float acc[PART_STRIDE];
+#pragma unroll
+    for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
+    const int r = radii[g];
+    if (r > 0 && !status->overflow) {
+        TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
+        for (int ty = box.y0; ty < box.y1; ++ty)
+            for (int tx = box.x0; tx < box.x1; ++tx) {
+                const int t = ty * tiles_x + tx;
+                int lo = tile_offsets[t], hi = tile_offsets[t + 1];
+                while (lo < hi) {  // first slot with id >= g
+                    int mid = (lo + hi) >> 1;
+                    if (ids[mid] < g)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                if (lo < tile_offsets[t + 1] && ids[lo] == g) {
+                    const float *src = partials + (size_t)lo * PART_STRIDE;
+#pragma unroll
+                    for (int k = 0; k < PART_STRIDE; ++k) acc[k] += src[k];
+                }
+            }
+    }
+    v_xy[2 * g] = acc[0];
+    v_xy[2 * g + 1] = acc[1];
+    v_conic[3 * g] = acc[2];
+    v_conic[3 * g + 1] = acc[3];
+    v_conic[3 * g + 2] = acc[4];
+    v_colors[3 * g] = acc[5];
+    v_colors[3 * g + 1] = acc[6];
+    v_colors[3 * g + 2] = acc[7];
+    v_opacity[g] = acc[8];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+struct gi2d_workspace {
+    int device = 0;
+    int tiles_cap = 0;
+    int *d_count = nullptr;     // [tiles_cap] per-tile counters / cursors, zero between calls
+    int *d_offsets = nullptr;   // [tiles_cap + 1]
+    int64_t ids_cap = 0;
+    int *d_ids = nullptr;
+    int64_t part_cap = 0;
+    float *d_partials = nullptr;
+    DevStatus *d_status = nullptr;
+    long long *h_status = nullptr;   // pinned: [0] total, [1] generation, [2] overflow generation
+    long long *h_status_dev = nullptr;
+    int64_t generation = 0;
+    int64_t overflow_ack = 0;
+    int tiles_x = 0, tiles_y = 0, n_binned = 0;
+    bool counters_dirty = false;  // counters may be non-zero (a binning was cut short)
+    bool counted = false;         // project_*_fwd accumulated counts for (n, tiles) below
+    int counted_n = 0, counted_tx = 0, counted_ty = 0;
+    int cull = 1;
+};
+
+#define HIP_TRY(expr)                                \
+    do {                                             \
+        hipError_t err__ = (expr);                   \
+        if (err__ != hipSuccess) return (int)err__;  \
+    } while (0)
+
+static inline int launch_status()
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GI2D_OK : (int)e;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+namespace {
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) ok = false;
+        if (ok && prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int gi2d_version(void) { return GI2D_VERSION; }
+
+const char *gi2d_error_string(int status)
+{
+    switch (status) {
+        case GI2D_OK: return "ok";
+        case GI2D_E_INVALID: return "invalid argument";
+        case GI2D_E_STATE: return "workspace holds no tile lists for this call";
+        case GI2D_E_CAPACITY: return "tile-list capacity exceeded";
+        case GI2D_E_PREV_OVERFLOW:
+            return "an earlier asynchronous frame overflowed the tile lists (its image is NaN); "
+                   "the workspace was grown, call again";
+        default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown error";
+    }
+}
+
+void gi2d_default_conv(gi2d_conv *c)
+{
+    c->pixel_offset = 0.0f;
+    c->center_bias = 0.0f;
+    c->alpha_cap = 1.0f;
+    c->alpha_min = 1.0f / 255.0f;
+    c->bg_weight = 0.0f;
+}
+
+int gi2d_workspace_create(int device, gi2d_workspace **out)
+{
+    if (!out) return GI2D_E_INVALID;
+    *out = nullptr;
+    DeviceGuard guard(device);
+    if (!guard.ok) return GI2D_E_INVALID;
+    gi2d_workspace *ws = new (std::nothrow) gi2d_workspace();
+    if (!ws) return (int)hipErrorOutOfMemory;
+    ws->device = device;
+    hipError_t e = hipMalloc(&ws->d_status, sizeof(DevStatus));
+    if (e == hipSuccess) e = hipMemset(ws->d_status, 0, sizeof(DevStatus));
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&ws->h_status, 4 * sizeof(long long), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        for (int i = 0; i < 4; ++i) ws->h_status[i] = 0;
+        e = hipHostGetDevicePointer((void **)&ws->h_status_dev, ws->h_status, 0);
+    }
+    if (e != hipSuccess) {
+        gi2d_workspace_destroy(ws);
+        return (int)e;
+    }
+    *out = ws;
+    return GI2D_OK;
+}
+
+int gi2d_workspace_destroy(gi2d_workspace *ws)
+{
+    if (!ws) return GI2D_OK;
+    DeviceGuard guard(ws->device);
+    (void)hipDeviceSynchronize();
+    if (ws->d_count) (void)hipFree(ws->d_count);
+    if (ws->d_offsets) (void)hipFree(ws->d_offsets);
+    if (ws->d_ids) (void)hipFree(ws->d_ids);
+    if (ws->d_partials) (void)hipFree(ws->d_partials);
+    if (ws->d_status) (void)hipFree(ws->d_status);
+    if (ws->h_status) (void)hipHostFree(ws->h_status);
+    delete ws;
+    return GI2D_OK;
+}
+
+// (Re)allocates the per-tile arrays; callers have made the device current.
+static int ensure_tiles(gi2d_workspace *ws, int T)
+{
+    if (T <= ws->tiles_cap) return GI2D_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (ws->d_count) (void)hipFree(ws->d_count);
+    if (ws->d_offsets) (void)hipFree(ws->d_offsets);
+    ws->d_count = ws->d_offsets = nullptr;
+    ws->tiles_cap = 0;
+    HIP_TRY(hipMalloc(&ws->d_count, sizeof(int) * (size_t)T));
+    HIP_TRY(hipMalloc(&ws->d_offsets, sizeof(int) * ((size_t)T + 1)));
+    HIP_TRY(hipMemset(ws->d_count, 0, sizeof(int) * (size_t)T));
+    HIP_TRY(hipMemset(ws->d_offsets, 0, sizeof(int) * ((size_t)T + 1)));
+    ws->tiles_cap = T;
+    ws->counters_dirty = false;
+    ws->counted = false;
+    ws->tiles_x = ws->tiles_y = 0;
+    return GI2D_OK;
+}
+
+static int ensure_ids(gi2d_workspace *ws, int64_t need)
+{
+    if (need <= ws->ids_cap) return GI2D_OK;
+    if (need >= (int64_t)INT_MAX) return GI2D_E_CAPACITY;
+    HIP_TRY(hipDeviceSynchronize());
+    if (ws->d_ids) (void)hipFree(ws->d_ids);
+    ws->d_ids = nullptr;
+    ws->ids_cap = 0;
+    HIP_TRY(hipMalloc(&ws->d_ids, sizeof(int) * (size_t)need));
+    ws->ids_cap = need;
+    return GI2D_OK;
+}
+
+int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t max_intersections, int max_tiles)
+{
+    if (!ws || max_intersections < 0 || max_tiles < 0) return GI2D_E_INVALID;
+    DeviceGuard guard(ws->device);
+    if (!guard.ok) return GI2D_E_INVALID;
+    int rc = ensure_tiles(ws, max_tiles);
+    if (rc != GI2D_OK) return rc;
+    return ensure_ids(ws, max_intersections);
+}
+
+int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
+{
+    if (!ws) return GI2D_E_INVALID;
+    switch (option) {
+        case GI2D_OPT_CULL: ws->cull = value ? 1 : 0; return GI2D_OK;
+        default: return GI2D_E_INVALID;
+    }
+}
+
+int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[6])
+{
+    if (!ws || !info) return GI2D_E_INVALID;
+    info[0] = ws->ids_cap;
+    info[1] = ws->h_status[1] == ws->generation ? ws->h_status[0] : -1;
+    info[2] = ws->generation;
+    info[3] = ws->tiles_x;
+    info[4] = ws->tiles_y;
+    info[5] = ws->n_binned;
+    return GI2D_OK;
+}
+
+static int check_proj_args(const void *a, const void *b, int N, int H, int W, int tiles_x,
+                           int tiles_y, const gi2d_conv *conv, const void *o0, const void *o1,
+                           const void *o2, const void *o3, const void *o4)
+{
+    if (N < 0 || H < 1 || W < 1 || !conv) return GI2D_E_INVALID;
+    if (tiles_x != cdiv(W, GI2D_BLOCK) || tiles_y != cdiv(H, GI2D_BLOCK)) return GI2D_E_INVALID;
+    if (N > 0 && (!a || !b || !o0 || !o1 || !o2 || !o3 || !o4)) return GI2D_E_INVALID;
+    return GI2D_OK;
+}
+
+// Prepares ws for a projection that also counts tiles.
+static int begin_fused_count(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream_t st)
+{
+    int rc = ensure_tiles(ws, tiles_x * tiles_y);
+    if (rc != GI2D_OK) return rc;
+    if (ws->counters_dirty || ws->counted) {
+        int T = ws->tiles_cap;
+        zero_ints_kernel<<<cdiv(T, 256), 256, 0, st>>>(ws->d_count, T);
+        rc = launch_status();
+        if (rc != GI2D_OK) return rc;
+    }
+    ws->counters_dirty = true;
+    ws->counted = true;
+    ws->counted_n = N;
+    ws->counted_tx = tiles_x;
+    ws->counted_ty = tiles_y;
+    return GI2D_OK;
+}
+
+int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int N, int H, int W,
+                              int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
+                              float *depths, int *radii, float *conics, int *num_tiles_hit,
+                              gi2d_workspace *ws, void *stream)
+{
+    int rc = check_proj_args(means2d, L_elements, N, H, W, tiles_x, tiles_y, conv, xys, depths,
+                             radii, conics, num_tiles_hit);
+    if (rc != GI2D_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int *tile_count = nullptr;
+    if (ws) {
+        rc = begin_fused_count(ws, N, tiles_x, tiles_y, st);
+        if (rc != GI2D_OK) return rc;
+        tile_count = ws->d_count;
+    }
+    if (N == 0) return GI2D_OK;
+    project_cholesky_fwd_kernel<<<cdiv(N, 256), 256, 0, st>>>(
+        means2d, L_elements, N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii,
+        conics, num_tiles_hit, tile_count);
+    return launch_status();
+}
+
+int gi2d_project_rs_fwd(const float *means2d, const float *scales, const float *rotation, int N,
+                        int H, int W, int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
+                        float *depths, int *radii, float *conics, int *num_tiles_hit,
+                        gi2d_workspace *ws, void *stream)
+{
+    int rc = check_proj_args(means2d, scales, N, H, W, tiles_x, tiles_y, conv, xys, depths, radii,
+                             conics, num_tiles_hit);
+    if (rc != GI2D_OK) return rc;
+    if (N > 0 && !rotation) return GI2D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int *tile_count = nullptr;
+    if (ws) {
+        rc = begin_fused_count(ws, N, tiles_x, tiles_y, st);
+        if (rc != GI2D_OK) return rc;
+        tile_count = ws->d_count;
+    }
+    if (N == 0) return GI2D_OK;
+    project_rs_fwd_kernel<<<cdiv(N, 256), 256, 0, st>>>(means2d, scales, rotation, N, H, W,
+                                                       tiles_x, tiles_y, conv->center_bias, xys,
+                                                       depths, radii, conics, num_tiles_hit,
+                                                       tile_count);
+    return launch_status();
+}
+
+int gi2d_project_cholesky_bwd(const float *means2d, const float *L_elements, int N, int H, int W,
+                              const float *v_xys, const float *v_conics, float *v_means2d,
+                              float *v_L_elements, void *stream)
+{
+    (void)means2d;
+    if (N < 0 || H < 1 || W < 1) return GI2D_E_INVALID;
+    if (N == 0) return GI2D_OK;
+    if (!L_elements || !v_xys || !v_conics || !v_means2d || !v_L_elements) return GI2D_E_INVALID;
+    project_cholesky_bwd_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
+        L_elements, N, H, W, v_xys, v_conics, v_means2d, v_L_elements);
+    return launch_status();
+}
+
+int gi2d_project_rs_bwd(const float *means2d, const float *scales, const float *rotation, int N,
+                        int H, int W, const float *v_xys, const float *v_conics, float *v_means2d,
+                        float *v_scales, float *v_rotation, void *stream)
+{
+    (void)means2d;
+    if (N < 0 || H < 1 || W < 1) return GI2D_E_INVALID;
+    if (N == 0) return GI2D_OK;
+    if (!scales || !rotation || !v_xys || !v_conics || !v_means2d || !v_scales || !v_rotation)
+        return GI2D_E_INVALID;
+    project_rs_bwd_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
+        scales, rotation, N, H, W, v_xys, v_conics, v_means2d, v_scales, v_rotation);
+    return launch_status();
+}
+
+int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
+                   int tiles_y, int flags, void *stream)
+{
+    if (!ws || N < 0 || tiles_x < 1 || tiles_y < 1) return GI2D_E_INVALID;
+    if ((int64_t)tiles_x * tiles_y >= (int64_t)INT_MAX / 2) return GI2D_E_INVALID;
+    if (N > 0 && (!xys || !radii)) return GI2D_E_INVALID;
+    DeviceGuard guard(ws->device);
+    if (!guard.ok) return GI2D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = tiles_x * tiles_y;
+    const bool nogrow = (flags & GI2D_BIN_NOGROW) != 0;
+    bool sync = (flags & GI2D_BIN_SYNC) != 0;
+    bool prev_overflow = false;
+
+    // an earlier asynchronous frame that did not fit: grow for it, tell the caller
+    if (ws->h_status[2] > ws->overflow_ack) {
+        ws->overflow_ack = ws->h_status[2];
+        prev_overflow = true;
+    }
+
+    bool counted = (flags & GI2D_BIN_COUNTED) && ws->counted && ws->counted_n == N &&
+                   ws->counted_tx == tiles_x && ws->counted_ty == tiles_y;
+    if ((flags & GI2D_BIN_COUNTED) && !counted) return GI2D_E_STATE;
+    if (!counted) {
+        if (nogrow && T > ws->tiles_cap) return GI2D_E_CAPACITY;
+        int rc = ensure_tiles(ws, T);
+        if (rc != GI2D_OK) return rc;
+        if (ws->counters_dirty || ws->counted) {
+            zero_ints_kernel<<<cdiv(ws->tiles_cap, 256), 256, 0, st>>>(ws->d_count, ws->tiles_cap);
+            rc = launch_status();
+            if (rc != GI2D_OK) return rc;
+        }
+        ws->counters_dirty = true;
+        if (N > 0) {
+            count_tiles_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, tiles_x, tiles_y,
+                                                             ws->d_count);
+            rc = launch_status();
+            if (rc != GI2D_OK) return rc;
+        }
+    }
+    ws->counted = false;
+
+    // Size the lists.  Steady state needs no synchronisation: the capacity keeps a 2x margin
+    // over the largest count seen from completed frames.
+    if (!nogrow) {
+        int64_t seen = ws->h_status[0];
+        // a new problem shape says nothing about its count: learn it once, synchronously
+        if (ws->ids_cap == 0 || N != ws->n_binned || tiles_x != ws->tiles_x ||
+            tiles_y != ws->tiles_y)
+            sync = true;
+        if (!sync && 2 * seen > ws->ids_cap) {
+            int rc = ensure_ids(ws, 2 * seen + 1024);
+            if (rc != GI2D_OK) return rc;
+        }
+    }
+
+    ws->generation += 1;
+    ws->tiles_x = tiles_x;
+    ws->tiles_y = tiles_y;
+    ws->n_binned = N;
+    scan_tiles_kernel<<<1, 1024, 0, st>>>(ws->d_count, ws->d_offsets, T,
+                                          sync && !nogrow ? (long long)INT_MAX - 1
+                                                          : (long long)ws->ids_cap,
+                                          ws->d_status, ws->h_status_dev, ws->generation);
+    int rc = launch_status();
+    if (rc != GI2D_OK) return rc;
+    ws->counters_dirty = false;  // the scan left the counters at zero
+
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(st));
+        int64_t total = ws->h_status[0];
+        if (total > ws->ids_cap) {
+            if (nogrow) {
+                ws->overflow_ack = ws->generation;  // reported here, not again on the next call
+                return GI2D_E_CAPACITY;
+            }
+            rc = ensure_ids(ws, total + total / 2 + 1024);
+            if (rc != GI2D_OK) return rc;
+        }
+    }
+    if (N > 0) {
+        ws->counters_dirty = true;
+        fill_tiles_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, tiles_x, tiles_y,
+                                                       ws->d_offsets, ws->d_count, ws->d_ids,
+                                                       ws->d_status);
+        rc = launch_status();
+        if (rc != GI2D_OK) return rc;
+        sort_tiles_kernel<<<T, WAVE, 0, st>>>(ws->d_offsets, ws->d_ids, ws->d_count, ws->d_status);
+        rc = launch_status();
+        if (rc != GI2D_OK) return rc;
+        ws->counters_dirty = false;  // the sort returned every cursor to zero
+    }
+    return prev_overflow ? GI2D_E_PREV_OVERFLOW : GI2D_OK;
+}
+
+int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_capacity,
+                   void *stream)
+{
+    if (!ws || !tile_offsets || ws->generation == 0) return ws ? GI2D_E_STATE : GI2D_E_INVALID;
+    DeviceGuard guard(ws->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ws->h_status[2] == ws->generation) return GI2D_E_CAPACITY;
+    const int T = ws->tiles_x * ws->tiles_y;
+    HIP_TRY(hipMemcpyAsync(tile_offsets, ws->d_offsets, sizeof(int) * ((size_t)T + 1),
+                           hipMemcpyDefault, st));
+    int64_t total = ws->h_status[0];
+    if (ids && total > 0) {
+        if (total > ids_capacity) return GI2D_E_CAPACITY;
+        HIP_TRY(hipMemcpyAsync(ids, ws->d_ids, sizeof(int) * (size_t)total, hipMemcpyDefault, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return GI2D_OK;
+}
+
+static int check_raster_args(gi2d_workspace *ws, int N, int H, int W, const gi2d_conv *conv)
+{
+    if (!ws || !conv || N < 0 || H < 1 || W < 1) return GI2D_E_INVALID;
+    if (ws->generation == 0) return GI2D_E_STATE;
+    if (ws->tiles_x != cdiv(W, GI2D_BLOCK) || ws->tiles_y != cdiv(H, GI2D_BLOCK) ||
+        ws->n_binned != N)
+        return GI2D_E_STATE;
+    return GI2D_OK;
+}
+
+int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *conics,
+                           const float *colors, const float *opacity, const float *background,
+                           int N, int H, int W, const gi2d_conv *conv, float *out_img,
+                           void *stream)
+{
+    int rc = check_raster_args(ws, N, H, W, conv);
+    if (rc != GI2D_OK) return rc;
+    if (!out_img || (N > 0 && (!xys || !conics || !colors || !opacity))) return GI2D_E_INVALID;
+    if (conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
+    DeviceGuard guard(ws->device);
+    hipStream_t st = (hipStream_t)stream;
+    float bg[3] = {0.f, 0.f, 0.f};
+    if (conv->bg_weight != 0.0f) {
+        // three floats, needed as kernel arguments
+        HIP_TRY(hipMemcpyAsync(bg, background, sizeof(bg), hipMemcpyDefault, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    const int T = ws->tiles_x * ws->tiles_y;
+    rasterize_sum_fwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
+                                                opacity, bg[0], bg[1], bg[2], H, W, ws->tiles_x,
+                                                *conv, ws->d_status, out_img);
+    return launch_status();
+}
+
+int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radii,
+                           const float *conics, const float *colors, const float *opacity, int N,
+                           int H, int W, const gi2d_conv *conv, const float *v_out, float *v_xys,
+                           float *v_conics, float *v_colors, float *v_opacity, void *stream)
+{
+    int rc = check_raster_args(ws, N, H, W, conv);
+    if (rc != GI2D_OK) return rc;
+    if (N == 0) return GI2D_OK;
+    if (!xys || !radii || !conics || !colors || !opacity || !v_out || !v_xys || !v_conics ||
+        !v_colors || !v_opacity)
+        return GI2D_E_INVALID;
+    DeviceGuard guard(ws->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (ws->part_cap < ws->ids_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (ws->d_partials) (void)hipFree(ws->d_partials);
+        ws->d_partials = nullptr;
+        ws->part_cap = 0;
+        HIP_TRY(hipMalloc(&ws->d_partials, sizeof(float) * PART_STRIDE * (size_t)ws->ids_cap));
+        ws->part_cap = ws->ids_cap;
+    }
+    const int T = ws->tiles_x * ws->tiles_y;
+    rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
+                                                opacity, H, W, ws->tiles_x, *conv, ws->cull,
+                                                ws->d_status, v_out, ws->d_partials);
+    rc = launch_status();
+    if (rc != GI2D_OK) return rc;
+    gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, ws->tiles_x, ws->tiles_y,
+                                                      ws->d_offsets, ws->d_ids, ws->d_partials,
+                                                      ws->d_status, v_xys, v_conics, v_colors,
+                                                      v_opacity);
+    return launch_status();
+}
+
+}  // extern "C"

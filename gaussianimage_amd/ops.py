@@ -1,0 +1,343 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+``project_gaussians_2d``, ``project_gaussians_2d_scale_rot`` and
+``rasterize_gaussians_sum`` keep the names, argument order, return tuples and
+error behaviour of the operators the reference imports
+(/root/reference/gaussianimage_cholesky.py:1-2,77,81-82;
+/root/reference/gaussianimage_rs.py:1-2,75-77) and run on the HIP kernels of
+``csrc/gi2d.hip`` through the C ABI.  PyTorch is used for device memory, the
+current stream and autograd bookkeeping only.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+from . import _lib
+from ._lib import BLOCK, Conv, check, default_conv, lib
+
+__all__ = ["project_gaussians_2d", "project_gaussians_2d_scale_rot", "rasterize_gaussians_sum",
+           "Workspace", "get_workspace", "set_conventions", "get_conventions"]
+
+_CONV = default_conv()
+
+
+def set_conventions(**kw):
+    """Override the conventions the reference cannot settle (see ``gi2d_conv``)."""
+    for k, v in kw.items():
+        if not hasattr(_CONV, k):
+            raise ValueError(f"unknown convention {k!r}")
+        setattr(_CONV, k, float(v))
+
+
+def get_conventions():
+    return {k: getattr(_CONV, k) for k, _ in Conv._fields_}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else ctypes.c_void_p(0)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _need_cuda(name, *tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                f"{name}: this operator runs on an AMD GPU through the HIP library only; got a "
+                f"{t.device} tensor (there is no CPU fallback)")
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class Workspace:
+    """Owns the device-side tile lists of one device (``gi2d_workspace``)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        h = ctypes.c_void_p()
+        check(lib.gi2d_workspace_create(self.device.index or 0, ctypes.byref(h)),
+              "gi2d_workspace_create")
+        self.handle = h
+        self.key = None       # identity of the tensors the current lists were built from
+        self.keep = None      # strong references: keeps their storage from being recycled
+        self.counted_key = None
+        self.sync_binning = os.environ.get("GI2D_SYNC", "0") == "1"
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                lib.gi2d_workspace_destroy(h)
+            except Exception:
+                pass
+
+    def info(self):
+        arr = (ctypes.c_int64 * 6)()
+        check(lib.gi2d_workspace_info(self.handle, arr), "gi2d_workspace_info")
+        return dict(capacity=arr[0], intersections=arr[1], generation=arr[2], tiles_x=arr[3],
+                    tiles_y=arr[4], num_gaussians=arr[5])
+
+    def reserve(self, max_intersections, max_tiles=0):
+        check(lib.gi2d_workspace_reserve(self.handle, int(max_intersections), int(max_tiles)),
+              "gi2d_workspace_reserve")
+
+    def set_cull(self, on):
+        check(lib.gi2d_workspace_set_option(self.handle, _lib.OPT_CULL, int(bool(on))),
+              "gi2d_workspace_set_option")
+
+    # -- binning ---------------------------------------------------------------------------
+    @staticmethod
+    def _key(xys, radii, H, W):
+        return (xys.data_ptr(), xys._version, radii.data_ptr(), radii._version, xys.shape[0], H, W)
+
+    def bin(self, xys, radii, H, W, flags=0, force=False):
+        """Builds (or reuses) the tile lists for these projected Gaussians."""
+        key = self._key(xys, radii, H, W)
+        if not force and key == self.key:
+            return
+        tiles_x, tiles_y = (W + BLOCK - 1) // BLOCK, (H + BLOCK - 1) // BLOCK
+        if self.sync_binning:
+            flags |= _lib.BIN_SYNC
+        if self.counted_key == key:
+            flags |= _lib.BIN_COUNTED
+        self.counted_key = None
+        self.key = None
+        rc = lib.gi2d_bin_tiles(self.handle, _ptr(xys), _ptr(radii), xys.shape[0], tiles_x,
+                                tiles_y, flags, _stream(xys.device))
+        if rc == _lib.GI2D_E_PREV_OVERFLOW:
+            raise _lib.Gi2dError(rc, "gi2d_bin_tiles")
+        check(rc, "gi2d_bin_tiles")
+        self.key = key
+        self.keep = (xys, radii)
+
+    def bins(self):
+        """(tile_offsets, ids) of the current lists as CPU int32 tensors (synchronises)."""
+        inf = self.info()
+        T = inf["tiles_x"] * inf["tiles_y"]
+        torch.cuda.synchronize(self.device)
+        inf = self.info()
+        total = max(int(inf["intersections"]), 0)
+        offs = torch.empty(T + 1, dtype=torch.int32, device=self.device)
+        ids = torch.empty(max(total, 1), dtype=torch.int32, device=self.device)
+        check(lib.gi2d_copy_bins(self.handle, _ptr(offs), _ptr(ids), ids.numel(),
+                                 _stream(self.device)), "gi2d_copy_bins")
+        return offs.cpu(), ids[:total].cpu()
+
+
+_WORKSPACES = {}
+_WS_LOCK = threading.Lock()
+
+
+def get_workspace(device):
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    with _WS_LOCK:
+        ws = _WORKSPACES.get(idx)
+        if ws is None:
+            ws = _WORKSPACES[idx] = Workspace(torch.device("cuda", idx))
+        return ws
+
+
+def _tile_bounds_check(name, H, W, tile_bounds):
+    tx, ty = (W + BLOCK - 1) // BLOCK, (H + BLOCK - 1) // BLOCK
+    if int(tile_bounds[0]) != tx or int(tile_bounds[1]) != ty:
+        raise ValueError(f"{name}: tile_bounds {tuple(tile_bounds)} does not match a {W}x{H} image "
+                         f"with {BLOCK}x{BLOCK} tiles (expected ({tx}, {ty}, 1))")
+    return tx, ty
+
+
+def _alloc_proj(N, device):
+    return (torch.empty(N, 2, dtype=torch.float32, device=device),
+            torch.empty(N, dtype=torch.float32, device=device),
+            torch.empty(N, dtype=torch.int32, device=device),
+            torch.empty(N, 3, dtype=torch.float32, device=device),
+            torch.empty(N, dtype=torch.int32, device=device))
+
+
+class _ProjectGaussians2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, L_elements, img_height, img_width, tile_bounds):
+        _need_cuda("project_gaussians_2d", means2d, L_elements)
+        tx, ty = _tile_bounds_check("project_gaussians_2d", img_height, img_width, tile_bounds)
+        m, L = _f32c(means2d), _f32c(L_elements)
+        N = m.shape[0]
+        xys, depths, radii, conics, nth = _alloc_proj(N, m.device)
+        ws = get_workspace(m.device)
+        ws.key = None
+        check(lib.gi2d_project_cholesky_fwd(_ptr(m), _ptr(L), N, img_height, img_width, tx, ty,
+                                            ctypes.byref(_CONV), _ptr(xys), _ptr(depths),
+                                            _ptr(radii), _ptr(conics), _ptr(nth), ws.handle,
+                                            _stream(m.device)), "gi2d_project_cholesky_fwd")
+        ws.counted_key = Workspace._key(xys, radii, img_height, img_width)
+        ctx.save_for_backward(m, L)
+        ctx.hw = (img_height, img_width)
+        ctx.mark_non_differentiable(depths, radii, nth)
+        return xys, depths, radii, conics, nth
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_nth):
+        m, L = ctx.saved_tensors
+        H, W = ctx.hw
+        N = m.shape[0]
+        v_xys = _f32c(v_xys) if v_xys is not None else torch.zeros_like(m)
+        v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros_like(L)
+        v_m, v_L = torch.empty_like(m), torch.empty_like(L)
+        check(lib.gi2d_project_cholesky_bwd(_ptr(m), _ptr(L), N, H, W, _ptr(v_xys),
+                                            _ptr(v_conics), _ptr(v_m), _ptr(v_L),
+                                            _stream(m.device)), "gi2d_project_cholesky_bwd")
+        return v_m, v_L, None, None, None
+
+
+class _ProjectGaussians2dScaleRot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, scales2d, rotation, img_height, img_width, tile_bounds):
+        _need_cuda("project_gaussians_2d_scale_rot", means2d, scales2d, rotation)
+        tx, ty = _tile_bounds_check("project_gaussians_2d_scale_rot", img_height, img_width,
+                                    tile_bounds)
+        m, s, r = _f32c(means2d), _f32c(scales2d), _f32c(rotation)
+        N = m.shape[0]
+        xys, depths, radii, conics, nth = _alloc_proj(N, m.device)
+        ws = get_workspace(m.device)
+        ws.key = None
+        check(lib.gi2d_project_rs_fwd(_ptr(m), _ptr(s), _ptr(r), N, img_height, img_width, tx, ty,
+                                      ctypes.byref(_CONV), _ptr(xys), _ptr(depths), _ptr(radii),
+                                      _ptr(conics), _ptr(nth), ws.handle, _stream(m.device)),
+              "gi2d_project_rs_fwd")
+        ws.counted_key = Workspace._key(xys, radii, img_height, img_width)
+        ctx.save_for_backward(m, s, r)
+        ctx.hw = (img_height, img_width)
+        ctx.mark_non_differentiable(depths, radii, nth)
+        return xys, depths, radii, conics, nth
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_nth):
+        m, s, r = ctx.saved_tensors
+        H, W = ctx.hw
+        N = m.shape[0]
+        v_xys = _f32c(v_xys) if v_xys is not None else torch.zeros_like(m)
+        v_conics = (_f32c(v_conics) if v_conics is not None else
+                    torch.zeros(N, 3, dtype=torch.float32, device=m.device))
+        v_m, v_s, v_r = torch.empty_like(m), torch.empty_like(s), torch.empty_like(r)
+        check(lib.gi2d_project_rs_bwd(_ptr(m), _ptr(s), _ptr(r), N, H, W, _ptr(v_xys),
+                                      _ptr(v_conics), _ptr(v_m), _ptr(v_s), _ptr(v_r),
+                                      _stream(m.device)), "gi2d_project_rs_bwd")
+        return v_m, v_s, v_r, None, None, None
+
+
+class _RasterizeGaussiansSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                img_width, background):
+        dev = xys.device
+        N = xys.shape[0]
+        # the tile lists are keyed on the caller's own xys/radii tensors, so that the passes of
+        # one model forward (gaussianimage_cholesky.py:81,89,95) share one binning
+        xys_c = xys.detach()
+        if xys_c.dtype != torch.float32 or not xys_c.is_contiguous():
+            xys_c = _f32c(xys)
+        radii_c = radii if (radii.dtype == torch.int32 and radii.is_contiguous()) else \
+            radii.to(torch.int32).contiguous()
+        con, col = _f32c(conics), _f32c(colors)
+        opa = _f32c(opacity).reshape(-1)
+        bg = _f32c(background)
+        ws = get_workspace(dev)
+        ws.bin(xys_c, radii_c, img_height, img_width)
+        out = torch.empty(img_height, img_width, 3, dtype=torch.float32, device=dev)
+        check(lib.gi2d_rasterize_sum_fwd(ws.handle, _ptr(xys_c), _ptr(con), _ptr(col), _ptr(opa),
+                                         _ptr(bg), N, img_height, img_width, ctypes.byref(_CONV),
+                                         _ptr(out), _stream(dev)), "gi2d_rasterize_sum_fwd")
+        ctx.save_for_backward(xys_c, radii_c, con, col, opa)
+        ctx.hw = (img_height, img_width)
+        ctx.opacity_shape = opacity.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        xys, radii, con, col, opa = ctx.saved_tensors
+        H, W = ctx.hw
+        N = xys.shape[0]
+        dev = xys.device
+        v_out = _f32c(v_out)
+        ws = get_workspace(dev)
+        ws.bin(xys, radii, H, W)  # reuses the forward's lists unless another frame replaced them
+        v_xy = torch.empty(N, 2, dtype=torch.float32, device=dev)
+        v_con = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        v_col = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        v_opa = torch.empty(N, dtype=torch.float32, device=dev)
+        check(lib.gi2d_rasterize_sum_bwd(ws.handle, _ptr(xys), _ptr(radii), _ptr(con), _ptr(col),
+                                         _ptr(opa), N, H, W, ctypes.byref(_CONV), _ptr(v_out),
+                                         _ptr(v_xy), _ptr(v_con), _ptr(v_col), _ptr(v_opa),
+                                         _stream(dev)), "gi2d_rasterize_sum_bwd")
+        return (v_xy, None, None, v_con, None, v_col, v_opa.reshape(ctx.opacity_shape), None, None,
+                None)
+
+
+def project_gaussians_2d(means2d, L_elements, img_height, img_width, tile_bounds):
+    """``gsplat.project_gaussians_2d.project_gaussians_2d`` of the reference
+    (/root/reference/gaussianimage_cholesky.py:77).  Returns
+    ``(xys[N,2], depths[N], radii[N] int32, conics[N,3], num_tiles_hit[N] int32)``."""
+    if means2d.ndimension() != 2 or means2d.shape[1] != 2:
+        raise ValueError("means2d must have shape (N, 2)")
+    if L_elements.ndimension() != 2 or L_elements.shape != (means2d.shape[0], 3):
+        raise ValueError("L_elements must have shape (N, 3)")
+    return _ProjectGaussians2d.apply(means2d, L_elements, int(img_height), int(img_width),
+                                     tuple(tile_bounds))
+
+
+def project_gaussians_2d_scale_rot(means2d, scales2d, rotation, img_height, img_width,
+                                   tile_bounds):
+    """``gsplat.project_gaussians_2d_scale_rot.project_gaussians_2d_scale_rot``
+    (/root/reference/gaussianimage_rs.py:75); ``rotation`` in radians, shape (N, 1)."""
+    N = means2d.shape[0]
+    if means2d.ndimension() != 2 or means2d.shape[1] != 2:
+        raise ValueError("means2d must have shape (N, 2)")
+    if scales2d.ndimension() != 2 or scales2d.shape != (N, 2):
+        raise ValueError("scales2d must have shape (N, 2)")
+    if rotation.numel() != N:
+        raise ValueError("rotation must have shape (N, 1)")
+    return _ProjectGaussians2dScaleRot.apply(means2d, scales2d, rotation, int(img_height),
+                                             int(img_width), tuple(tile_bounds))
+
+
+def rasterize_gaussians_sum(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
+                            img_height, img_width, BLOCK_H=16, BLOCK_W=16, background=None,
+                            return_alpha=False):
+    """``gsplat.rasterize_sum.rasterize_gaussians_sum`` of the reference
+    (/root/reference/gaussianimage_cholesky.py:81-82): the accumulated sum
+    ``out[p] = sum_g colors[g] * min(cap, opacity[g] * exp(-sigma_g(p)))`` over the Gaussians
+    binned to the pixel's tile; ``[H, W, 3]`` float32."""
+    if colors.ndimension() != 2:
+        raise ValueError("colors must have dimensions (N, D)")
+    if opacity.ndimension() != 2:
+        raise ValueError("opacity must have dimensions (N, 1)")
+    if colors.shape[1] != 3:
+        raise ValueError("this build rasterizes 3 colour channels; got %d" % colors.shape[1])
+    if int(BLOCK_H) != BLOCK or int(BLOCK_W) != BLOCK:
+        raise ValueError(f"tile size is fixed at {BLOCK}x{BLOCK} (the reference's train.py:54)")
+    _need_cuda("rasterize_gaussians_sum", xys, conics, colors, opacity)
+    if background is None:
+        background = torch.ones(3, dtype=torch.float32, device=xys.device)
+    if background.shape[0] != colors.shape[1]:
+        raise ValueError("background and colors must have the same number of channels")
+    N = xys.shape[0]
+    for name, t in (("radii", radii), ("conics", conics), ("colors", colors),
+                    ("opacity", opacity)):
+        if t.shape[0] != N:
+            raise ValueError(f"{name} has {t.shape[0]} rows, xys has {N}")
+    out = _RasterizeGaussiansSum.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
+                                       int(img_height), int(img_width), background)
+    if return_alpha:
+        # never requested by the reference's 2D models; alpha of a sum has no transmittance
+        # meaning, so the accumulated weight of a white colour set is returned
+        ones = torch.ones_like(colors)
+        alpha = _RasterizeGaussiansSum.apply(xys.detach(), depths, radii, conics.detach(), 
+                                             num_tiles_hit, ones, opacity.detach(),
+                                             int(img_height), int(img_width), background)[..., 0]
+        return out, alpha
+    return out

@@ -1,0 +1,130 @@
+/*
+ * gi2d.h -- C ABI of the MI355X (gfx950) accumulated-summation 2D Gaussian
+ * rasterizer: projection, tile binning, rasterize_sum forward and backward.
+ *
+ * The reference reaches this path through three Python operators of an
+ * un-vendored `gsplat` extension (/root/reference/.gitmodules:1-3); the native
+ * FFI under them is not part of the reference tree, so each entry point below
+ * cites the Python call site whose work it performs.
+ *
+ * Conventions: every pointer is a DEVICE pointer on the workspace's device
+ * unless named h_*; tensors are dense row-major fp32 / int32; `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  All functions
+ * return 0 on success, a negative GI2D_E_* code for a rejected argument or
+ * state, or a positive hipError_t.  Nothing throws.  A workspace serves one
+ * host thread and one stream at a time.
+ */
+#ifndef GI2D_H
+#define GI2D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GI2D_VERSION 100 /* 0.1.0 */
+#define GI2D_BLOCK 16    /* tile edge in pixels; the reference hard-codes 16 (train.py:54) */
+
+#define GI2D_OK 0
+#define GI2D_E_INVALID (-1)       /* bad pointer / size / unsupported block size           */
+#define GI2D_E_STATE (-2)         /* e.g. rasterize before any bin_tiles on this workspace  */
+#define GI2D_E_CAPACITY (-3)      /* intersections exceed the reserved list capacity        */
+#define GI2D_E_PREV_OVERFLOW (-4) /* an EARLIER asynchronous frame overflowed (its image is */
+                                  /* NaN); the workspace has been grown, call again         */
+
+/* flags of gi2d_bin_tiles */
+#define GI2D_BIN_SYNC 1    /* wait for the intersection count and size the lists exactly     */
+#define GI2D_BIN_COUNTED 2 /* per-tile counts were already accumulated by gi2d_project_*_fwd */
+#define GI2D_BIN_NOGROW 4  /* never reallocate (fixed-memory callers)                        */
+
+/* Conventions the reference cannot settle (its operator source is absent);
+ * see gi2d_default_conv for the defaults. */
+typedef struct gi2d_conv {
+    float pixel_offset; /* pixel (j,i) is sampled at (j+off, i+off)            */
+    float center_bias;  /* xys = 0.5*W*x + 0.5*W + bias                         */
+    float alpha_cap;    /* alpha = min(cap, opacity*exp(-sigma))                */
+    float alpha_min;    /* pairs with alpha < alpha_min contribute nothing      */
+    float bg_weight;    /* out += bg_weight*background (0 = background ignored) */
+} gi2d_conv;
+
+typedef struct gi2d_workspace gi2d_workspace;
+
+int gi2d_version(void);
+const char *gi2d_error_string(int status);
+void gi2d_default_conv(gi2d_conv *conv);
+
+/* Workspace: owns the per-tile counters, offsets, Gaussian-id lists and the
+ * backward partial-sum slab, so that the three raster passes of
+ * GaussianImage_Cholesky.forward() (gaussianimage_cholesky.py:81,89,95) share
+ * one binning and no call needs a host synchronisation in steady state. */
+int gi2d_workspace_create(int device, gi2d_workspace **out);
+int gi2d_workspace_destroy(gi2d_workspace *ws);
+int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t max_intersections, int max_tiles);
+/* Options: GI2D_OPT_CULL (default 1) lets the backward skip pixels outside a
+ * Gaussian's support rectangle; 0 evaluates every pixel of every listed tile
+ * (same results, used by the tests to prove that). */
+#define GI2D_OPT_CULL 1
+int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value);
+/* info[0]=list capacity, [1]=intersections of the last COMPLETED binning,
+ * [2]=binning generation, [3]=tiles_x, [4]=tiles_y, [5]=Gaussians binned */
+int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[6]);
+
+/* project_gaussians_2d(means2d, L_elements, H, W, tile_bounds)
+ * (gaussianimage_cholesky.py:77).  Outputs xys[N,2], depths[N], radii[N],
+ * conics[N,3], num_tiles_hit[N].  With ws != NULL the per-tile counts of the
+ * binning are accumulated in the same launch (then pass GI2D_BIN_COUNTED). */
+int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int N, int H, int W,
+                              int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
+                              float *depths, int *radii, float *conics, int *num_tiles_hit,
+                              gi2d_workspace *ws, void *stream);
+
+/* project_gaussians_2d_scale_rot(means2d, scales, rotation, H, W, tile_bounds)
+ * (gaussianimage_rs.py:75). */
+int gi2d_project_rs_fwd(const float *means2d, const float *scales, const float *rotation, int N,
+                        int H, int W, int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
+                        float *depths, int *radii, float *conics, int *num_tiles_hit,
+                        gi2d_workspace *ws, void *stream);
+
+/* Backward of the two projections, reached through loss.backward()
+ * (gaussianimage_cholesky.py:116, gaussianimage_rs.py:87). */
+int gi2d_project_cholesky_bwd(const float *means2d, const float *L_elements, int N, int H, int W,
+                              const float *v_xys, const float *v_conics, float *v_means2d,
+                              float *v_L_elements, void *stream);
+int gi2d_project_rs_bwd(const float *means2d, const float *scales, const float *rotation, int N,
+                        int H, int W, const float *v_xys, const float *v_conics, float *v_means2d,
+                        float *v_scales, float *v_rotation, void *stream);
+
+/* Tile binning: the hidden first half of rasterize_gaussians_sum
+ * (gaussianimage_cholesky.py:81 passes xys, radii, num_tiles_hit for it).
+ * Groups (tile, Gaussian) intersections by tile, ascending Gaussian id inside
+ * a tile. */
+int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
+                   int tiles_y, int flags, void *stream);
+
+/* Copies the current lists out (device or host destinations): tile_offsets
+ * gets tiles+1 ints, ids up to ids_capacity ints.  Synchronises the stream. */
+int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_capacity,
+                   void *stream);
+
+/* rasterize_gaussians_sum(xys, depths, radii, conics, num_tiles_hit, colors,
+ * opacity, H, W, BLOCK_H, BLOCK_W, background=..., return_alpha=False)
+ * forward (gaussianimage_cholesky.py:81-82): out_img[H,W,3], using the lists
+ * of the last gi2d_bin_tiles on ws.  colors[N,3], opacity[N], background[3]. */
+int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *conics,
+                           const float *colors, const float *opacity, const float *background,
+                           int N, int H, int W, const gi2d_conv *conv, float *out_img,
+                           void *stream);
+
+/* Its backward (gaussianimage_cholesky.py:116): v_out[H,W,3] ->
+ * v_xys[N,2], v_conics[N,3], v_colors[N,3], v_opacity[N].  Deterministic: no
+ * floating-point atomics. */
+int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radii,
+                           const float *conics, const float *colors, const float *opacity, int N,
+                           int H, int W, const gi2d_conv *conv, const float *v_out, float *v_xys,
+                           float *v_conics, float *v_colors, float *v_opacity, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GI2D_H */

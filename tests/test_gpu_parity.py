@@ -1,0 +1,359 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Integer outputs (radii, tile counts, tile lists) are compared bit for bit;
+the image to 1e-5 absolute and gradients to 1e-4 relative (the tolerances the task states).
+
+Pixels whose value hinges on the last bits of exp() at the alpha >= 1/255 cut (the oracle
+reports that margin) are set aside in image comparisons: no two exp implementations agree
+there, and a flipped pair moves a pixel by ~1/255."""
+import numpy as np
+import pytest
+import torch
+
+from gaussianimage_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+IMG_ATOL = 1e-5
+GRAD_RTOL = 1e-4
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _maxrel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gaussianimage_amd import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+CASES = [(48, 64, 64, 0, 1.0), (80, 96, 512, 1, 1.0), (33, 50, 300, 2, 2.0),
+         (512, 768, 5000, 1, 1.0), (100, 130, 2000, 3, 4.0)]
+
+
+@pytest.mark.parametrize("H,W,N,seed,fp", CASES)
+def test_project_cholesky_forward(ops, oracle, H, W, N, seed, fp):
+    means, L, _, _ = synth.cholesky_inputs(N, seed=seed, footprint=fp)
+    tb = oracle.tile_bounds(H, W)
+    got = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+    ref = oracle.project_cholesky_fwd(means.numpy(), L.numpy(), H, W)
+    assert np.array_equal(_np(got[2]), ref[2]), "radii"
+    assert np.array_equal(_np(got[4]), ref[4]), "num_tiles_hit"
+    assert np.array_equal(_np(got[0]), ref[0]), "xys"
+    assert np.array_equal(_np(got[3]), ref[3]), "conics"
+    assert not _np(got[1]).any()
+    assert got[2].dtype == torch.int32 and got[4].dtype == torch.int32
+
+
+@pytest.mark.parametrize("H,W,N,seed,fp", CASES)
+def test_project_rs_forward(ops, oracle, H, W, N, seed, fp):
+    means, sc, rot, _, _ = synth.rs_inputs(N, seed=seed, footprint=fp)
+    tb = oracle.tile_bounds(H, W)
+    got = ops.project_gaussians_2d_scale_rot(means.to(DEV), sc.to(DEV), rot.to(DEV), H, W, tb)
+    ref = oracle.project_rs_fwd(means.numpy(), sc.numpy(), rot.numpy(), H, W)
+    # sincos of the device and of libm differ in the last bits: the ceil() of the radius may
+    # flip for a Gaussian sitting on an integer, nothing else may move
+    bad = _np(got[2]) != ref[2]
+    assert bad.sum() <= max(1, N // 2000)
+    assert np.abs(_np(got[2]) - ref[2]).max() <= 1
+    np.testing.assert_allclose(_np(got[0]), ref[0], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(_np(got[3]), ref[3], rtol=2e-5, atol=1e-6)
+    same = ~bad
+    assert np.array_equal(_np(got[4])[same], ref[4][same])
+
+
+def _project_and_bin(ops, oracle, H, W, N, seed, fp):
+    means, L, col, op = synth.cholesky_inputs(N, seed=seed, footprint=fp)
+    tb = oracle.tile_bounds(H, W)
+    xys, depths, radii, conics, nth = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+    ws = ops.get_workspace(DEV)
+    ws.bin(xys, radii, H, W, force=True)
+    return means, L, col, op, (xys, depths, radii, conics, nth), ws
+
+
+@pytest.mark.parametrize("H,W,N,seed,fp", CASES + [(64, 64, 3000, 5, 6.0)])
+def test_tile_lists_match_bit_for_bit(ops, oracle, H, W, N, seed, fp):
+    *_, proj, ws = _project_and_bin(ops, oracle, H, W, N, seed, fp)
+    offs, ids = ws.bins()
+    r_offs, r_ids = oracle.bin_tiles(_np(proj[0]), _np(proj[2]), H, W)
+    assert np.array_equal(offs.numpy(), r_offs)
+    assert np.array_equal(ids.numpy(), r_ids)
+    assert ws.info()["intersections"] == len(r_ids) == int(_np(proj[4]).sum())
+
+
+def test_tile_lists_long_lists_and_standalone_count(ops, oracle):
+    """Lists longer than one wave (LDS sort) and longer than the LDS sort limit (in-place sort
+    in memory); binning from caller-made tensors (no fused count from a projection)."""
+    H, W, N = 48, 48, 6000
+    g = torch.Generator().manual_seed(11)
+    xys = torch.rand(N, 2, generator=g) * torch.tensor([W, H])
+    radii = torch.randint(1, 40, (N,), generator=g, dtype=torch.int32)
+    radii[::7] = 0
+    ws = ops.get_workspace(DEV)
+    ws.bin(xys.to(DEV), radii.to(DEV), H, W, force=True)
+    offs, ids = ws.bins()
+    r_offs, r_ids = oracle.bin_tiles(xys.numpy(), radii.numpy(), H, W)
+    assert np.diff(r_offs).max() > 4096 and np.diff(r_offs).min() > 64
+    assert np.array_equal(offs.numpy(), r_offs)
+    assert np.array_equal(ids.numpy(), r_ids)
+
+
+@pytest.mark.parametrize("H,W,N,seed,fp", CASES)
+def test_rasterize_forward(ops, oracle, H, W, N, seed, fp):
+    means, L, col, op, proj, ws = _project_and_bin(ops, oracle, H, W, N, seed, fp)
+    op = 0.2 + 0.8 * torch.rand(N, 1, generator=torch.Generator().manual_seed(seed))
+    xys, depths, radii, conics, nth = proj
+    img = ops.rasterize_gaussians_sum(xys, depths, radii, conics, nth, col.to(DEV), op.to(DEV), H,
+                                      W, 16, 16, background=torch.ones(3, device=DEV))
+    assert img.shape == (H, W, 3) and img.dtype == torch.float32 and img.is_contiguous()
+    offs, ids = oracle.bin_tiles(_np(xys), _np(radii), H, W)
+    ref, margin = oracle.rasterize_sum_fwd(_np(xys), _np(conics), col.numpy(), op.numpy(), H, W,
+                                           offs, ids, want_margin=True)
+    ok = margin > 1e-4
+    assert ok.mean() > 0.995
+    err = np.abs(_np(img) - ref)
+    assert err[ok].max() <= IMG_ATOL
+    # a set-aside pixel can differ by at most a few cut-off contributions
+    assert err.max() <= 3.0 * (1 / 255) * max(1.0, float(col.max()))
+
+
+@pytest.mark.parametrize("H,W,N,seed,fp", CASES)
+def test_rasterize_backward(ops, oracle, H, W, N, seed, fp):
+    means, L, col, op, proj, ws = _project_and_bin(ops, oracle, H, W, N, seed, fp)
+    op = 0.2 + 0.8 * torch.rand(N, 1, generator=torch.Generator().manual_seed(seed))
+    xys, depths, radii, conics, nth = proj
+    v_out = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(seed + 100))
+    leaves = [xys.detach().clone().requires_grad_(True),
+              conics.detach().clone().requires_grad_(True),
+              col.to(DEV).requires_grad_(True), op.to(DEV).requires_grad_(True)]
+    img = ops.rasterize_gaussians_sum(leaves[0], depths, radii, leaves[1], nth, leaves[2],
+                                      leaves[3], H, W, 16, 16)
+    (img * v_out.to(DEV)).sum().backward()
+    offs, ids = oracle.bin_tiles(_np(xys), _np(radii), H, W)
+    ref = oracle.rasterize_sum_bwd(_np(xys), _np(conics), col.numpy(), op.numpy(), H, W, offs, ids,
+                                   v_out.numpy())
+    for name, leaf, r in zip(("xys", "conics", "colors", "opacity"), leaves, ref):
+        assert leaf.grad.shape == leaf.shape
+        assert _maxrel(_np(leaf.grad), r.reshape(leaf.shape)) <= GRAD_RTOL, name
+
+
+def test_backward_culling_changes_nothing(ops, oracle):
+    """The support-rectangle culling of the backward is exact: same bits with it off."""
+    H, W, N = 80, 96, 800
+    means, L, col, op, proj, ws = _project_and_bin(ops, oracle, H, W, N, 4, 2.5)
+    op = (0.05 + 0.95 * torch.rand(N, 1, generator=torch.Generator().manual_seed(0))).to(DEV)
+    op[::9] = 0.003  # below the cut: contributes nowhere
+    xys, depths, radii, conics, nth = proj
+    v_out = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    grads = []
+    for cull in (True, False):
+        ws.set_cull(cull)
+        leaves = [xys.detach().clone().requires_grad_(True),
+                  conics.detach().clone().requires_grad_(True),
+                  col.to(DEV).requires_grad_(True), op.clone().requires_grad_(True)]
+        img = ops.rasterize_gaussians_sum(leaves[0], depths, radii, leaves[1], nth, leaves[2],
+                                          leaves[3], H, W, 16, 16)
+        (img * v_out).sum().backward()
+        grads.append([_np(l.grad) for l in leaves])
+    ws.set_cull(True)
+    for a, b in zip(*grads):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("N,seed", [(64, 0), (3000, 1)])
+def test_project_backward(ops, oracle, N, seed):
+    H, W = 80, 96
+    tb = oracle.tile_bounds(H, W)
+    gen = torch.Generator().manual_seed(seed)
+    v_xy, v_con = torch.randn(N, 2, generator=gen), torch.randn(N, 3, generator=gen)
+    means, L, _, _ = synth.cholesky_inputs(N, seed=seed)
+    m, l = means.to(DEV).requires_grad_(True), L.to(DEV).requires_grad_(True)
+    xys, _, _, con, _ = ops.project_gaussians_2d(m, l, H, W, tb)
+    ((xys * v_xy.to(DEV)).sum() + (con * v_con.to(DEV)).sum()).backward()
+    r_m, r_l = oracle.project_cholesky_bwd(means.numpy(), L.numpy(), H, W, v_xy.numpy(),
+                                           v_con.numpy())
+    assert _maxrel(_np(m.grad), r_m) <= GRAD_RTOL
+    assert _maxrel(_np(l.grad), r_l) <= GRAD_RTOL
+    means, sc, rot, _, _ = synth.rs_inputs(N, seed=seed)
+    m, s, r = (means.to(DEV).requires_grad_(True), sc.to(DEV).requires_grad_(True),
+               rot.to(DEV).requires_grad_(True))
+    xys, _, _, con, _ = ops.project_gaussians_2d_scale_rot(m, s, r, H, W, tb)
+    ((xys * v_xy.to(DEV)).sum() + (con * v_con.to(DEV)).sum()).backward()
+    r_m, r_s, r_r = oracle.project_rs_bwd(means.numpy(), sc.numpy(), rot.numpy(), H, W,
+                                          v_xy.numpy(), v_con.numpy())
+    assert _maxrel(_np(m.grad), r_m) <= GRAD_RTOL
+    assert _maxrel(_np(s.grad), r_s) <= GRAD_RTOL
+    assert _maxrel(_np(r.grad), r_r) <= GRAD_RTOL
+
+
+def test_model_sequence_cholesky_end_to_end(ops, oracle):
+    """The caller's own sequence (gaussianimage_cholesky.py:62,74,76-85,104,116): tanh / bound
+    -> project -> rasterize -> clamp -> permute -> mse -> backward, against the oracle chain."""
+    from oracle import torch_oracle as to
+    H, W, N = 80, 96, 512
+    xyz, chol, feat = synth.cholesky_params(N, seed=2)
+    gt = synth.target_image(H, W)
+    params = [p.to(DEV).requires_grad_(True) for p in (xyz, chol, feat)]
+    tb = oracle.tile_bounds(H, W)
+    bound = torch.tensor([0.5, 0.0, 0.5], device=DEV)
+    xys, depths, radii, conics, nth = ops.project_gaussians_2d(torch.tanh(params[0]),
+                                                               params[1] + bound, H, W, tb)
+    out = ops.rasterize_gaussians_sum(xys, depths, radii, conics, nth, params[2],
+                                      torch.ones(N, 1, device=DEV), H, W, 16, 16,
+                                      background=torch.ones(3, device=DEV), return_alpha=False)
+    out = torch.clamp(out, 0, 1).view(-1, H, W, 3).permute(0, 3, 1, 2).contiguous()
+    loss = torch.nn.functional.mse_loss(out, gt.to(DEV))
+    loss.backward()
+    ref_params = [p.double().requires_grad_(True) for p in (xyz, chol, feat)]
+    ref_img = to.model_forward_cholesky(*ref_params, H, W)
+    ref_loss = torch.nn.functional.mse_loss(ref_img, gt.double())
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-6
+    for p, r in zip(params, ref_params):
+        assert _maxrel(_np(p.grad), r.grad.numpy()) <= 5e-4
+
+
+def test_model_sequence_rs_end_to_end(ops, oracle):
+    """gaussianimage_rs.py:55-60,74-80,86-87."""
+    import math
+    from oracle import torch_oracle as to
+    H, W, N = 80, 96, 512
+    xyz, scaling, rotation, feat = synth.rs_params(N, seed=3)
+    gt = synth.target_image(H, W)
+    params = [p.to(DEV).requires_grad_(True) for p in (xyz, scaling, rotation, feat)]
+    tb = oracle.tile_bounds(H, W)
+    xys, depths, radii, conics, nth = ops.project_gaussians_2d_scale_rot(
+        torch.tanh(params[0]), torch.abs(params[1] + 0.5), torch.sigmoid(params[2]) * 2 * math.pi,
+        H, W, tb)
+    out = ops.rasterize_gaussians_sum(xys, depths, radii, conics, nth, params[3],
+                                      torch.ones(N, 1, device=DEV), H, W, 16, 16,
+                                      background=torch.ones(3, device=DEV), return_alpha=False)
+    out = torch.clamp(out, 0, 1).view(-1, H, W, 3).permute(0, 3, 1, 2).contiguous()
+    loss = torch.nn.functional.mse_loss(out, gt.to(DEV))
+    loss.backward()
+    ref_params = [p.double().requires_grad_(True) for p in (xyz, scaling, rotation, feat)]
+    ref_loss = torch.nn.functional.mse_loss(to.model_forward_rs(*ref_params, H, W), gt.double())
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 2e-6
+    for p, r in zip(params, ref_params):
+        assert _maxrel(_np(p.grad), r.grad.numpy()) <= 5e-4
+
+
+def test_three_passes_share_one_binning_and_runs_are_bit_reproducible(ops, oracle):
+    H, W, N = 96, 128, 2000
+    means, L, col, op = synth.cholesky_inputs(N, seed=6, footprint=2.0)
+    tb = oracle.tile_bounds(H, W)
+    imgs, gens = [], []
+    for rep in range(2):
+        proj = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+        ws = ops.get_workspace(DEV)
+        g0 = ws.info()["generation"]
+        a = ops.rasterize_gaussians_sum(*proj, col.to(DEV), op.to(DEV), H, W, 16, 16)
+        b = ops.rasterize_gaussians_sum(*proj, col.to(DEV) * 0.5, op.to(DEV), H, W, 16, 16)
+        c = ops.rasterize_gaussians_sum(*proj, torch.ones(N, 3, device=DEV), op.to(DEV), H, W, 16,
+                                        16)
+        gens.append(ws.info()["generation"] - g0)
+        imgs.append([_np(a), _np(b), _np(c)])
+    assert gens == [1, 1], "one binning per projected frame, reused by the three passes"
+    for x, y in zip(*imgs):
+        assert np.array_equal(x, y)
+
+
+def test_empty_and_degenerate_inputs(ops, oracle):
+    H, W = 40, 56
+    tb = oracle.tile_bounds(H, W)
+    z = lambda *s, **k: torch.zeros(*s, device=DEV, **k)
+    proj = ops.project_gaussians_2d(z(0, 2), z(0, 3), H, W, tb)
+    assert [t.shape[0] for t in proj] == [0] * 5
+    img = ops.rasterize_gaussians_sum(*proj, z(0, 3), z(0, 1), H, W, 16, 16)
+    assert img.shape == (H, W, 3) and not _np(img).any()
+    # zero determinant, off-image, NaN parameter: early-outs with zero outputs
+    means = torch.tensor([[0.0, 0.0], [30.0, 30.0], [0.2, -0.3], [0.1, 0.1]])
+    L = torch.tensor([[1.0, 0.5, 0.0], [1.0, 0.0, 1.0], [0.8, 0.1, 0.9], [float("nan"), 0.0, 1.0]])
+    got = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+    ref = oracle.project_cholesky_fwd(means.numpy(), L.numpy(), H, W)
+    for g, r in zip(got, ref):
+        assert np.array_equal(_np(g), r)
+    col = torch.rand(4, 3)
+    img = ops.rasterize_gaussians_sum(*got, col.to(DEV), torch.ones(4, 1, device=DEV), H, W, 16,
+                                      16)
+    offs, ids = oracle.bin_tiles(ref[0], ref[2], H, W)
+    rimg = oracle.rasterize_sum_fwd(ref[0], ref[3], col.numpy(), np.ones((4, 1)), H, W, offs, ids)
+    assert np.abs(_np(img) - rimg).max() <= IMG_ATOL
+
+
+def test_fixed_capacity_overflow_is_reported(ops, oracle):
+    from gaussianimage_amd import _lib
+    H, W, N = 64, 64, 1000
+    means, L, col, op = synth.cholesky_inputs(N, seed=8, footprint=3.0)
+    tb = oracle.tile_bounds(H, W)
+    ws = ops.Workspace(DEV)
+    ws.reserve(100, 16)
+    proj = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+    with pytest.raises(_lib.Gi2dError) as ei:
+        ws.bin(proj[0], proj[2], H, W, flags=_lib.BIN_SYNC | _lib.BIN_NOGROW, force=True)
+    assert ei.value.status == _lib.GI2D_E_CAPACITY
+    # without NOGROW the same workspace grows and bins correctly
+    ws.bin(proj[0], proj[2], H, W, flags=_lib.BIN_SYNC, force=True)
+    offs, ids = ws.bins()
+    r_offs, r_ids = oracle.bin_tiles(_np(proj[0]), _np(proj[2]), H, W)
+    assert np.array_equal(ids.numpy(), r_ids) and np.array_equal(offs.numpy(), r_offs)
+
+
+def test_baseline_config_full_size(ops, oracle):
+    """BASELINE config 2: 768x512, 30k Gaussians, Cholesky, forward + backward."""
+    H, W, N = 512, 768, 30000
+    means, L, col, op, proj, ws = _project_and_bin(ops, oracle, H, W, N, 1, 1.0)
+    xys, depths, radii, conics, nth = proj
+    leaves = [xys.detach().clone().requires_grad_(True),
+              conics.detach().clone().requires_grad_(True), col.to(DEV).requires_grad_(True)]
+    opa = torch.ones(N, 1, device=DEV)
+    img = ops.rasterize_gaussians_sum(leaves[0], depths, radii, leaves[1], nth, leaves[2], opa, H,
+                                      W, 16, 16)
+    v_out = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(5))
+    (img * v_out.to(DEV)).sum().backward()
+    offs, ids = oracle.bin_tiles(_np(xys), _np(radii), H, W)
+    g_offs, g_ids = ws.bins()
+    assert np.array_equal(g_offs.numpy(), offs) and np.array_equal(g_ids.numpy(), ids)
+    ref, margin = oracle.rasterize_sum_fwd(_np(xys), _np(conics), col.numpy(), np.ones((N, 1)), H,
+                                           W, offs, ids, want_margin=True)
+    ok = margin > 1e-4
+    assert ok.mean() > 0.995
+    assert np.abs(_np(img) - ref)[ok].max() <= IMG_ATOL
+    rg = oracle.rasterize_sum_bwd(_np(xys), _np(conics), col.numpy(), np.ones((N, 1)), H, W, offs,
+                                  ids, v_out.numpy())
+    for leaf, r in zip(leaves, rg[:3]):
+        assert _maxrel(_np(leaf.grad), r) <= GRAD_RTOL
+
+
+def test_4k_frame_properties(ops, oracle):
+    """BASELINE config 5 size (3840x2160, 200k): size-independent properties instead of a full
+    oracle pass -- linearity in the colours, list bookkeeping, and an oracle check of a band."""
+    H, W, N = 2160, 3840, 200000
+    means, L, col, op = synth.cholesky_inputs(N, seed=1)
+    tb = oracle.tile_bounds(H, W)
+    proj = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+    opa = torch.ones(N, 1, device=DEV)
+    c1, c2 = col.to(DEV), torch.rand(N, 3, generator=torch.Generator().manual_seed(9)).to(DEV)
+    a = ops.rasterize_gaussians_sum(*proj, c1, opa, H, W, 16, 16)
+    b = ops.rasterize_gaussians_sum(*proj, c2, opa, H, W, 16, 16)
+    ab = ops.rasterize_gaussians_sum(*proj, c1 + c2, opa, H, W, 16, 16)
+    assert float((a + b - ab).abs().max()) <= 2e-5
+    ws = ops.get_workspace(DEV)
+    assert ws.info()["intersections"] == int(proj[4].sum().item())
+    # oracle on the top 64 rows only (same lists restricted to those tile rows)
+    Hb = 64
+    xys, radii, conics = _np(proj[0]), _np(proj[2]), _np(proj[3])
+    offs, ids = oracle.bin_tiles(xys, radii, H, W)
+    nb = tb[0] * (Hb // 16)
+    ref, margin = oracle.rasterize_sum_fwd(xys, conics, col.numpy(), np.ones((N, 1)), Hb, W,
+                                           offs[:nb + 1], ids[:offs[nb]], want_margin=True)
+    ok = margin > 1e-4
+    assert np.abs(_np(a[:Hb]) - ref)[ok].max() <= IMG_ATOL
