@@ -48,6 +48,7 @@ SIGNATURES = {
     "gi2d_workspace_destroy": (_i, [_vp]),
     "gi2d_workspace_reserve": (_i, [_vp, _i64, _i]),
     "gi2d_workspace_set_option": (_i, [_vp, _i, _i]),
+    "gi2d_workspace_set_rows": (_i, [_vp, _i, _i]),
     "gi2d_workspace_info": (_i, [_vp, ctypes.POINTER(_i64)]),
     "gi2d_project_cholesky_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _convp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp]),

@@ -93,7 +93,7 @@ __device__ __forceinline__ void project_tail(int g, float mx, float my, float sx
                                              float syy, int H, int W, int tiles_x, int tiles_y,
                                              float center_bias, float *xys, float *depths,
                                              int *radii, float *conics, int *num_tiles_hit,
-                                             int *tile_count)
+                                             int *tile_count, int row0, int row1)
 {
     float ca = 0.f, cb = 0.f, cc = 0.f, radius = 0.f, cx = 0.f, cy = 0.f;
     int irad = 0, area = 0;
@@ -117,8 +117,10 @@ __device__ __forceinline__ void project_tail(int g, float mx, float my, float sx
     conics[3 * g + 2] = cc;
     num_tiles_hit[g] = area;
     if (tile_count != nullptr && irad > 0 && area > 0) {
-        for (int ty = box.y0; ty < box.y1; ++ty)
-            for (int tx = box.x0; tx < box.x1; ++tx) atomicAdd(&tile_count[ty * tiles_x + tx], 1);
+        const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = box.x0; tx < box.x1; ++tx)
+                atomicAdd(&tile_count[(ty - row0) * tiles_x + tx], 1);
     }
 }
 
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
     const float *__restrict__ means, const float *__restrict__ L, int N, int H, int W, int tiles_x,
     int tiles_y, float center_bias, float *__restrict__ xys, float *__restrict__ depths,
     int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count)
+    int *tile_count, int row0, int row1)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
     float sxy = l11 * l21;
     float syy = l21 * l21 + l22 * l22;
     project_tail(g, means[2 * g], means[2 * g + 1], sxx, sxy, syy, H, W, tiles_x, tiles_y,
-                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count);
+                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count, row0, row1);
 }
 
 __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     const float *__restrict__ rot, int N, int H, int W, int tiles_x, int tiles_y,
     float center_bias, float *__restrict__ xys, float *__restrict__ depths,
     int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count)
+    int *tile_count, int row0, int row1)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     float sxy = c * s * (q1 - q2);
     float syy = s * s * q1 + c * c * q2;
     project_tail(g, means[2 * g], means[2 * g + 1], sxx, sxy, syy, H, W, tiles_x, tiles_y,
-                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count);
+                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count, row0, row1);
 }
 
 // dL/dSigma from dL/dconic: with C = Sigma^-1 and V = [[va, vb/2],[vb/2, vc]], G = -C V C;
@@ -249,16 +251,18 @@ __global__ __launch_bounds__(256) void zero_ints_kernel(int *p, int n)
 
 __global__ __launch_bounds__(256) void count_tiles_kernel(const float *__restrict__ xys,
                                                            const int *__restrict__ radii, int N,
-                                                           int tiles_x, int tiles_y,
-                                                           int *tile_count)
+                                                           int tiles_x, int tiles_y, int row0,
+                                                           int row1, int *tile_count)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     int r = radii[g];
     if (r <= 0) return;
     TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
-    for (int ty = box.y0; ty < box.y1; ++ty)
-        for (int tx = box.x0; tx < box.x1; ++tx) atomicAdd(&tile_count[ty * tiles_x + tx], 1);
+    const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = box.x0; tx < box.x1; ++tx)
+            atomicAdd(&tile_count[(ty - row0) * tiles_x + tx], 1);
 }
 
 // One workgroup: exclusive scan of the per-tile counts into tile_offsets[T+1]; leaves the
@@ -307,7 +311,8 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(int *tile_count, int *
 
 __global__ __launch_bounds__(256) void fill_tiles_kernel(const float *__restrict__ xys,
                                                           const int *__restrict__ radii, int N,
-                                                          int tiles_x, int tiles_y,
+                                                          int tiles_x, int tiles_y, int row0,
+                                                          int row1,
                                                           const int *__restrict__ tile_offsets,
                                                           int *tile_cursor, int *ids,
                                                           const DevStatus *status)
@@ -318,9 +323,10 @@ __global__ __launch_bounds__(256) void fill_tiles_kernel(const float *__restrict
     int r = radii[g];
     if (r <= 0) return;
     TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
-    for (int ty = box.y0; ty < box.y1; ++ty)
+    const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
+    for (int ty = y0; ty < y1; ++ty)
         for (int tx = box.x0; tx < box.x1; ++tx) {
-            int t = ty * tiles_x + tx;
+            int t = (ty - row0) * tiles_x + tx;
             int pos = atomicAdd(&tile_cursor[t], 1);
             ids[tile_offsets[t] + pos] = g;
         }
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     const int *__restrict__ tile_offsets, const int *__restrict__ ids,
     const float *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacity, float bg0, float bg1,
-    float bg2, int H, int W, int tiles_x, gi2d_conv cv, const DevStatus *status,
+    float bg2, int H, int W, int tiles_x, int row0, gi2d_conv cv, const DevStatus *status,
     float *__restrict__ out)
 {
     __shared__ float4 s_a[256];  // gx, gy, conic a, conic b
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     __shared__ float s_c[256];   // colour b
     const int tid = threadIdx.x;
     const int t = blockIdx.x;
-    const int tx = t % tiles_x, ty = t / tiles_x;
+    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
     const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
     const bool inside = (i < H) && (j < W);
     const float px = (float)j + cv.pixel_offset, py = (float)i + cv.pixel_offset;
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
         b = b + cv.bg_weight * bg2;
     }
     if (inside) {
-        float *o = out + 3 * ((size_t)i * W + j);
+        float *o = out + 3 * ((size_t)(i - row0 * GI2D_BLOCK) * W + j);
         o[0] = r;
         o[1] = g;
         o[2] = b;
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     const int *__restrict__ tile_offsets, const int *__restrict__ ids,
     const float *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacity, int H, int W,
-    int tiles_x, gi2d_conv cv, int cull, const DevStatus *status,
+    int tiles_x, int row0, gi2d_conv cv, int cull, const DevStatus *status,
     const float *__restrict__ v_out, float *__restrict__ partials)
 {
     __shared__ float s_v[3][256];
@@ -495,12 +501,12 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     const int t = blockIdx.x;
     const int beg = tile_offsets[t], end = tile_offsets[t + 1];
     if (beg == end) return;
-    const int tx = t % tiles_x, ty = t / tiles_x;
+    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
     {
         const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
         if (i < H && j < W) {
-            const float *p = v_out + 3 * ((size_t)i * W + j);
+            const float *p = v_out + 3 * ((size_t)(i - row0 * GI2D_BLOCK) * W + j);
             v0 = p[0];
             v1 = p[1];
             v2 = p[2];
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
 
 __global__ __launch_bounds__(256) void gather_grads_kernel(
     const float *__restrict__ xys, const int *__restrict__ radii, int N, int tiles_x, int tiles_y,
-    const int *__restrict__ tile_offsets, const int *__restrict__ ids,
+    int row0, int row1, const int *__restrict__ tile_offsets, const int *__restrict__ ids,
     const float *__restrict__ partials, const DevStatus *status, float *__restrict__ v_xy,
     float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity)
 {
@@ -601,9 +607,10 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(
     const int r = radii[g];
     if (r > 0 && !status->overflow) {
         TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
-        for (int ty = box.y0; ty < box.y1; ++ty)
+        const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
+        for (int ty = y0; ty < y1; ++ty)
             for (int tx = box.x0; tx < box.x1; ++tx) {
-                const int t = ty * tiles_x + tx;
+                const int t = (ty - row0) * tiles_x + tx;
                 int lo = tile_offsets[t], hi = tile_offsets[t + 1];
                 while (lo < hi) {  // first slot with id >= g
                     int mid = (lo + hi) >> 1;
@@ -649,9 +656,11 @@ struct gi2d_workspace {
     int64_t generation = 0;
     int64_t overflow_ack = 0;
     int tiles_x = 0, tiles_y = 0, n_binned = 0;
+    int row0 = 0, row1 = INT_MAX;          // tile rows requested by the caller (a band)
+    int bin_row0 = 0, bin_row1 = 0;        // tile rows of the current lists
     bool counters_dirty = false;  // counters may be non-zero (a binning was cut short)
     bool counted = false;         // project_*_fwd accumulated counts for (n, tiles) below
-    int counted_n = 0, counted_tx = 0, counted_ty = 0;
+    int counted_n = 0, counted_tx = 0, counted_ty = 0, counted_r0 = 0, counted_r1 = 0;
     int cull = 1;
 };
 
@@ -805,7 +814,15 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
     }
 }
 
-int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[6])
+int gi2d_workspace_set_rows(gi2d_workspace *ws, int row_begin, int row_end)
+{
+    if (!ws || row_begin < 0 || row_end < row_begin) return GI2D_E_INVALID;
+    ws->row0 = row_begin;
+    ws->row1 = row_end;
+    return GI2D_OK;
+}
+
+int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[8])
 {
     if (!ws || !info) return GI2D_E_INVALID;
     info[0] = ws->ids_cap;
@@ -814,6 +831,8 @@ int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[6])
     info[3] = ws->tiles_x;
     info[4] = ws->tiles_y;
     info[5] = ws->n_binned;
+    info[6] = ws->bin_row0;
+    info[7] = ws->bin_row1;
     return GI2D_OK;
 }
 
@@ -830,7 +849,8 @@ static int check_proj_args(const void *a, const void *b, int N, int H, int W, in
 // Prepares ws for a projection that also counts tiles.
 static int begin_fused_count(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream_t st)
 {
-    int rc = ensure_tiles(ws, tiles_x * tiles_y);
+    const int r0 = min(ws->row0, tiles_y), r1 = min(ws->row1, tiles_y);
+    int rc = ensure_tiles(ws, max(1, (r1 - r0) * tiles_x));
     if (rc != GI2D_OK) return rc;
     if (ws->counters_dirty || ws->counted) {
         int T = ws->tiles_cap;
@@ -843,6 +863,8 @@ static int begin_fused_count(gi2d_workspace *ws, int N, int tiles_x, int tiles_y
     ws->counted_n = N;
     ws->counted_tx = tiles_x;
     ws->counted_ty = tiles_y;
+    ws->counted_r0 = r0;
+    ws->counted_r1 = r1;
     return GI2D_OK;
 }
 
@@ -864,7 +886,7 @@ int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int
     if (N == 0) return GI2D_OK;
     project_cholesky_fwd_kernel<<<cdiv(N, 256), 256, 0, st>>>(
         means2d, L_elements, N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii,
-        conics, num_tiles_hit, tile_count);
+        conics, num_tiles_hit, tile_count, ws ? ws->counted_r0 : 0, ws ? ws->counted_r1 : 0);
     return launch_status();
 }
 
@@ -888,7 +910,8 @@ int gi2d_project_rs_fwd(const float *means2d, const float *scales, const float *
     project_rs_fwd_kernel<<<cdiv(N, 256), 256, 0, st>>>(means2d, scales, rotation, N, H, W,
                                                        tiles_x, tiles_y, conv->center_bias, xys,
                                                        depths, radii, conics, num_tiles_hit,
-                                                       tile_count);
+                                                       tile_count, ws ? ws->counted_r0 : 0,
+                                                       ws ? ws->counted_r1 : 0);
     return launch_status();
 }
 
@@ -928,7 +951,8 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     DeviceGuard guard(ws->device);
     if (!guard.ok) return GI2D_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    const int T = tiles_x * tiles_y;
+    const int r0 = min(ws->row0, tiles_y), r1 = min(ws->row1, tiles_y);
+    const int T = (r1 - r0) * tiles_x;
     const bool nogrow = (flags & GI2D_BIN_NOGROW) != 0;
     bool sync = (flags & GI2D_BIN_SYNC) != 0;
     bool prev_overflow = false;
@@ -940,11 +964,12 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     }
 
     bool counted = (flags & GI2D_BIN_COUNTED) && ws->counted && ws->counted_n == N &&
-                   ws->counted_tx == tiles_x && ws->counted_ty == tiles_y;
+                   ws->counted_tx == tiles_x && ws->counted_ty == tiles_y &&
+                   ws->counted_r0 == r0 && ws->counted_r1 == r1;
     if ((flags & GI2D_BIN_COUNTED) && !counted) return GI2D_E_STATE;
     if (!counted) {
         if (nogrow && T > ws->tiles_cap) return GI2D_E_CAPACITY;
-        int rc = ensure_tiles(ws, T);
+        int rc = ensure_tiles(ws, max(1, T));
         if (rc != GI2D_OK) return rc;
         if (ws->counters_dirty || ws->counted) {
             zero_ints_kernel<<<cdiv(ws->tiles_cap, 256), 256, 0, st>>>(ws->d_count, ws->tiles_cap);
@@ -953,8 +978,8 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
         }
         ws->counters_dirty = true;
         if (N > 0) {
-            count_tiles_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, tiles_x, tiles_y,
-                                                             ws->d_count);
+            count_tiles_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, tiles_x, tiles_y, r0,
+                                                             r1, ws->d_count);
             rc = launch_status();
             if (rc != GI2D_OK) return rc;
         }
@@ -967,7 +992,7 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
         int64_t seen = ws->h_status[0];
         // a new problem shape says nothing about its count: learn it once, synchronously
         if (ws->ids_cap == 0 || N != ws->n_binned || tiles_x != ws->tiles_x ||
-            tiles_y != ws->tiles_y)
+            tiles_y != ws->tiles_y || r0 != ws->bin_row0 || r1 != ws->bin_row1)
             sync = true;
         if (!sync && 2 * seen > ws->ids_cap) {
             int rc = ensure_ids(ws, 2 * seen + 1024);
@@ -979,6 +1004,8 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     ws->tiles_x = tiles_x;
     ws->tiles_y = tiles_y;
     ws->n_binned = N;
+    ws->bin_row0 = r0;
+    ws->bin_row1 = r1;
     scan_tiles_kernel<<<1, 1024, 0, st>>>(ws->d_count, ws->d_offsets, T,
                                           sync && !nogrow ? (long long)INT_MAX - 1
                                                           : (long long)ws->ids_cap,
@@ -999,9 +1026,9 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
             if (rc != GI2D_OK) return rc;
         }
     }
-    if (N > 0) {
+    if (N > 0 && T > 0) {
         ws->counters_dirty = true;
-        fill_tiles_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, tiles_x, tiles_y,
+        fill_tiles_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, tiles_x, tiles_y, r0, r1,
                                                        ws->d_offsets, ws->d_count, ws->d_ids,
                                                        ws->d_status);
         rc = launch_status();
@@ -1022,7 +1049,7 @@ int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipStreamSynchronize(st));
     if (ws->h_status[2] == ws->generation) return GI2D_E_CAPACITY;
-    const int T = ws->tiles_x * ws->tiles_y;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     HIP_TRY(hipMemcpyAsync(tile_offsets, ws->d_offsets, sizeof(int) * ((size_t)T + 1),
                            hipMemcpyDefault, st));
     int64_t total = ws->h_status[0];
@@ -1061,10 +1088,11 @@ int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *co
         HIP_TRY(hipMemcpyAsync(bg, background, sizeof(bg), hipMemcpyDefault, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    const int T = ws->tiles_x * ws->tiles_y;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (T == 0) return GI2D_OK;
     rasterize_sum_fwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
                                                 opacity, bg[0], bg[1], bg[2], H, W, ws->tiles_x,
-                                                *conv, ws->d_status, out_img);
+                                                ws->bin_row0, *conv, ws->d_status, out_img);
     return launch_status();
 }
 
@@ -1089,14 +1117,17 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
         HIP_TRY(hipMalloc(&ws->d_partials, sizeof(float) * PART_STRIDE * (size_t)ws->ids_cap));
         ws->part_cap = ws->ids_cap;
     }
-    const int T = ws->tiles_x * ws->tiles_y;
-    rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
-                                                opacity, H, W, ws->tiles_x, *conv, ws->cull,
-                                                ws->d_status, v_out, ws->d_partials);
-    rc = launch_status();
-    if (rc != GI2D_OK) return rc;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (T > 0) {
+        rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
+                                                    opacity, H, W, ws->tiles_x, ws->bin_row0,
+                                                    *conv, ws->cull, ws->d_status, v_out,
+                                                    ws->d_partials);
+        rc = launch_status();
+        if (rc != GI2D_OK) return rc;
+    }
     gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, ws->tiles_x, ws->tiles_y,
-                                                      ws->d_offsets, ws->d_ids, ws->d_partials,
+                                                      ws->bin_row0, ws->bin_row1, ws->d_offsets, ws->d_ids, ws->d_partials,
                                                       ws->d_status, v_xys, v_conics, v_colors,
                                                       v_opacity);
     return launch_status();

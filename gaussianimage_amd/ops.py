@@ -78,14 +78,21 @@ class Workspace:
                 pass
 
     def info(self):
-        arr = (ctypes.c_int64 * 6)()
+        arr = (ctypes.c_int64 * 8)()
         check(lib.gi2d_workspace_info(self.handle, arr), "gi2d_workspace_info")
         return dict(capacity=arr[0], intersections=arr[1], generation=arr[2], tiles_x=arr[3],
-                    tiles_y=arr[4], num_gaussians=arr[5])
+                    tiles_y=arr[4], num_gaussians=arr[5], row_begin=arr[6], row_end=arr[7])
 
     def reserve(self, max_intersections, max_tiles=0):
         check(lib.gi2d_workspace_reserve(self.handle, int(max_intersections), int(max_tiles)),
               "gi2d_workspace_reserve")
+
+    def set_rows(self, row_begin=0, row_end=2 ** 31 - 1):
+        """Restricts binning/rasterisation to tile rows [row_begin, row_end) (a band)."""
+        check(lib.gi2d_workspace_set_rows(self.handle, int(row_begin), int(row_end)),
+              "gi2d_workspace_set_rows")
+        self.key = None
+        self.counted_key = None
 
     def set_cull(self, on):
         check(lib.gi2d_workspace_set_option(self.handle, _lib.OPT_CULL, int(bool(on))),
@@ -119,7 +126,7 @@ class Workspace:
     def bins(self):
         """(tile_offsets, ids) of the current lists as CPU int32 tensors (synchronises)."""
         inf = self.info()
-        T = inf["tiles_x"] * inf["tiles_y"]
+        T = inf["tiles_x"] * (inf["row_end"] - inf["row_begin"])
         torch.cuda.synchronize(self.device)
         inf = self.info()
         total = max(int(inf["intersections"]), 0)

@@ -1,0 +1,136 @@
+"""Allocation-free driver of the hot path: project -> bin -> rasterize_sum (and back).
+
+``FramePipeline`` owns every buffer of one frame configuration (operator inputs are handed in
+as device tensors) and issues the C-ABI calls back to back on the current stream without host
+synchronisation.  It is what ``bench.py`` times and what the tile-row sharding builds on; the
+autograd operators in ``ops.py`` are the drop-in boundary for the reference's models.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BLOCK, check, lib
+from .ops import Workspace, _ptr, _stream, get_conventions
+
+__all__ = ["FramePipeline"]
+
+
+class FramePipeline:
+    """One frame configuration: ``N`` Gaussians on an ``H x W`` image, Cholesky or RS.
+
+    ``rows=(r0, r1)`` restricts binning and rasterisation to tile rows ``[r0, r1)`` of the
+    frame (tile-row sharding); the image buffer then holds only that band.
+    """
+
+    def __init__(self, num_points, H, W, kind="cholesky", device="cuda:0", rows=None,
+                 workspace=None):
+        if kind not in ("cholesky", "rs"):
+            raise ValueError("kind must be 'cholesky' or 'rs'")
+        self.N, self.H, self.W, self.kind = int(num_points), int(H), int(W), kind
+        self.device = torch.device(device)
+        self.tiles_x = (self.W + BLOCK - 1) // BLOCK
+        self.tiles_y = (self.H + BLOCK - 1) // BLOCK
+        self.rows = (0, self.tiles_y) if rows is None else (int(rows[0]), int(rows[1]))
+        if not (0 <= self.rows[0] <= self.rows[1] <= self.tiles_y):
+            raise ValueError(f"rows {self.rows} outside [0, {self.tiles_y}]")
+        self.band_y0 = self.rows[0] * BLOCK
+        self.band_h = max(0, min(self.H, self.rows[1] * BLOCK) - self.band_y0)
+        self.ws = workspace or Workspace(self.device)
+        self.conv = _lib.default_conv(**get_conventions())
+        d, N = self.device, self.N
+        f32, i32 = torch.float32, torch.int32
+        self.xys = torch.empty(N, 2, dtype=f32, device=d)
+        self.depths = torch.empty(N, dtype=f32, device=d)
+        self.radii = torch.empty(N, dtype=i32, device=d)
+        self.conics = torch.empty(N, 3, dtype=f32, device=d)
+        self.num_tiles_hit = torch.empty(N, dtype=i32, device=d)
+        self.image = torch.empty(self.band_h, self.W, 3, dtype=f32, device=d)
+        self.background = torch.ones(3, dtype=f32, device=d)
+        # backward buffers are made on first use
+        self.v_xys = self.v_conics = self.v_colors = self.v_opacity = None
+        self.v_means = self.v_cov_a = self.v_cov_b = None
+        self._set_rows()
+
+    def _set_rows(self):
+        check(lib.gi2d_workspace_set_rows(self.ws.handle, self.rows[0], self.rows[1]),
+              "gi2d_workspace_set_rows")
+
+    # -- forward ---------------------------------------------------------------------------
+    def project(self, means, cov_a, cov_b=None):
+        """``cov_a`` = L_elements[N,3] (Cholesky) or scales[N,2] with ``cov_b`` = rotation[N,1]."""
+        st = _stream(self.device)
+        outs = (_ptr(self.xys), _ptr(self.depths), _ptr(self.radii), _ptr(self.conics),
+                _ptr(self.num_tiles_hit))
+        if self.kind == "cholesky":
+            check(lib.gi2d_project_cholesky_fwd(_ptr(means), _ptr(cov_a), self.N, self.H, self.W,
+                                                self.tiles_x, self.tiles_y,
+                                                ctypes.byref(self.conv), *outs, self.ws.handle,
+                                                st), "gi2d_project_cholesky_fwd")
+        else:
+            check(lib.gi2d_project_rs_fwd(_ptr(means), _ptr(cov_a), _ptr(cov_b), self.N, self.H,
+                                          self.W, self.tiles_x, self.tiles_y,
+                                          ctypes.byref(self.conv), *outs, self.ws.handle, st),
+                  "gi2d_project_rs_fwd")
+
+    def bin(self, flags=_lib.BIN_COUNTED):
+        check(lib.gi2d_bin_tiles(self.ws.handle, _ptr(self.xys), _ptr(self.radii), self.N,
+                                 self.tiles_x, self.tiles_y, flags, _stream(self.device)),
+              "gi2d_bin_tiles")
+        self.ws.key = None
+
+    def rasterize(self, colors, opacity, out=None):
+        out = self.image if out is None else out
+        check(lib.gi2d_rasterize_sum_fwd(self.ws.handle, _ptr(self.xys), _ptr(self.conics),
+                                         _ptr(colors), _ptr(opacity), _ptr(self.background),
+                                         self.N, self.H, self.W, ctypes.byref(self.conv),
+                                         _ptr(out), _stream(self.device)),
+              "gi2d_rasterize_sum_fwd")
+        return out
+
+    def forward(self, means, cov_a, cov_b, colors, opacity):
+        """project -> bin -> rasterize; returns the (band of the) image, ``[band_h, W, 3]``."""
+        self._set_rows()
+        self.project(means, cov_a, cov_b)
+        self.bin()
+        return self.rasterize(colors, opacity)
+
+    # -- backward --------------------------------------------------------------------------
+    def _alloc_backward(self, cov_a, cov_b):
+        d, N, f32 = self.device, self.N, torch.float32
+        self.v_xys = torch.empty(N, 2, dtype=f32, device=d)
+        self.v_conics = torch.empty(N, 3, dtype=f32, device=d)
+        self.v_colors = torch.empty(N, 3, dtype=f32, device=d)
+        self.v_opacity = torch.empty(N, dtype=f32, device=d)
+        self.v_means = torch.empty(N, 2, dtype=f32, device=d)
+        self.v_cov_a = torch.empty_like(cov_a)
+        self.v_cov_b = torch.empty_like(cov_b) if cov_b is not None else None
+
+    def backward(self, means, cov_a, cov_b, colors, opacity, v_image):
+        """Gradients of ``sum(image * v_image)``: returns
+        ``(v_means, v_cov_a, v_cov_b, v_colors, v_opacity)`` (buffers owned by the pipeline)."""
+        if self.v_xys is None:
+            self._alloc_backward(cov_a, cov_b)
+        st = _stream(self.device)
+        check(lib.gi2d_rasterize_sum_bwd(self.ws.handle, _ptr(self.xys), _ptr(self.radii),
+                                         _ptr(self.conics), _ptr(colors), _ptr(opacity), self.N,
+                                         self.H, self.W, ctypes.byref(self.conv), _ptr(v_image),
+                                         _ptr(self.v_xys), _ptr(self.v_conics),
+                                         _ptr(self.v_colors), _ptr(self.v_opacity), st),
+              "gi2d_rasterize_sum_bwd")
+        if self.kind == "cholesky":
+            check(lib.gi2d_project_cholesky_bwd(_ptr(means), _ptr(cov_a), self.N, self.H, self.W,
+                                                _ptr(self.v_xys), _ptr(self.v_conics),
+                                                _ptr(self.v_means), _ptr(self.v_cov_a), st),
+                  "gi2d_project_cholesky_bwd")
+        else:
+            check(lib.gi2d_project_rs_bwd(_ptr(means), _ptr(cov_a), _ptr(cov_b), self.N, self.H,
+                                          self.W, _ptr(self.v_xys), _ptr(self.v_conics),
+                                          _ptr(self.v_means), _ptr(self.v_cov_a),
+                                          _ptr(self.v_cov_b), st), "gi2d_project_rs_bwd")
+        return self.v_means, self.v_cov_a, self.v_cov_b, self.v_colors, self.v_opacity
+
+    def intersections(self):
+        """Number of (tile, Gaussian) intersections of the last binning (synchronises)."""
+        torch.cuda.synchronize(self.device)
+        return int(self.ws.info()["intersections"])

@@ -66,9 +66,16 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t max_intersections, int ma
  * (same results, used by the tests to prove that). */
 #define GI2D_OPT_CULL 1
 int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value);
+/* Tile-row band: binning and rasterisation cover tile rows [row_begin,row_end)
+ * of the frame only (row_end is clipped to the frame); out_img / v_out then
+ * point at the band's first pixel row.  Default: the whole frame.  This is
+ * the partition of the tile-row sharding across GPUs; it has no counterpart
+ * in the single-GPU reference. */
+int gi2d_workspace_set_rows(gi2d_workspace *ws, int row_begin, int row_end);
 /* info[0]=list capacity, [1]=intersections of the last COMPLETED binning,
- * [2]=binning generation, [3]=tiles_x, [4]=tiles_y, [5]=Gaussians binned */
-int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[6]);
+ * [2]=binning generation, [3]=tiles_x, [4]=tiles_y, [5]=Gaussians binned,
+ * [6],[7]=tile rows [begin,end) of the current lists */
+int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[8]);
 
 /* project_gaussians_2d(means2d, L_elements, H, W, tile_bounds)
  * (gaussianimage_cholesky.py:77).  Outputs xys[N,2], depths[N], radii[N],
