@@ -13,6 +13,9 @@
 #include "../../include/gi2d.h"
 
 #define WAVE 64
+// Workgroup size of the per-Gaussian kernels that issue scattered atomics: one wave, so that
+// the launch spreads over every CU (a CU retires scattered atomics slowly; many CUs do not).
+#define PG_THREADS 64
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -884,7 +887,7 @@ int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int
         tile_count = ws->d_count;
     }
     if (N == 0) return GI2D_OK;
-    project_cholesky_fwd_kernel<<<cdiv(N, 256), 256, 0, st>>>(
+    project_cholesky_fwd_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(
         means2d, L_elements, N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii,
         conics, num_tiles_hit, tile_count, ws ? ws->counted_r0 : 0, ws ? ws->counted_r1 : 0);
     return launch_status();
@@ -907,7 +910,7 @@ int gi2d_project_rs_fwd(const float *means2d, const float *scales, const float *
         tile_count = ws->d_count;
     }
     if (N == 0) return GI2D_OK;
-    project_rs_fwd_kernel<<<cdiv(N, 256), 256, 0, st>>>(means2d, scales, rotation, N, H, W,
+    project_rs_fwd_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(means2d, scales, rotation, N, H, W,
                                                        tiles_x, tiles_y, conv->center_bias, xys,
                                                        depths, radii, conics, num_tiles_hit,
                                                        tile_count, ws ? ws->counted_r0 : 0,
@@ -978,7 +981,7 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
         }
         ws->counters_dirty = true;
         if (N > 0) {
-            count_tiles_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, tiles_x, tiles_y, r0,
+            count_tiles_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(xys, radii, N, tiles_x, tiles_y, r0,
                                                              r1, ws->d_count);
             rc = launch_status();
             if (rc != GI2D_OK) return rc;
@@ -1028,7 +1031,7 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     }
     if (N > 0 && T > 0) {
         ws->counters_dirty = true;
-        fill_tiles_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, tiles_x, tiles_y, r0, r1,
+        fill_tiles_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(xys, radii, N, tiles_x, tiles_y, r0, r1,
                                                        ws->d_offsets, ws->d_count, ws->d_ids,
                                                        ws->d_status);
         rc = launch_status();
