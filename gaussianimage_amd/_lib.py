@@ -29,6 +29,14 @@ OPT_CULL = 1
 BLOCK = 16
 
 
+class AdanHyper(ctypes.Structure):
+    """Mirror of ``gi2d_adan_hyper``."""
+    _fields_ = [("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double),
+                ("beta3", ctypes.c_double), ("eps", ctypes.c_double),
+                ("weight_decay", ctypes.c_double), ("no_prox", ctypes.c_int),
+                ("step", ctypes.c_int)]
+
+
 class Conv(ctypes.Structure):
     """Mirror of ``gi2d_conv``."""
     _fields_ = [("pixel_offset", ctypes.c_float), ("center_bias", ctypes.c_float),
@@ -59,6 +67,8 @@ SIGNATURES = {
     "gi2d_bin_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gi2d_copy_bins": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "gi2d_rasterize_sum_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp]),
+    "gi2d_adan_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(AdanHyper), _vp,
+                            _vp]),
     "gi2d_rasterize_sum_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
                                     _vp, _vp, _vp, _vp]),
 }

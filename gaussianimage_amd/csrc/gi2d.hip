@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <math.h>
 #include <new>
 
 #include "../../include/gi2d.h"
@@ -327,12 +328,36 @@ __global__ __launch_bounds__(256) void fill_tiles_kernel(const float *__restrict
     if (r <= 0) return;
     TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
     const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = box.x0; tx < box.x1; ++tx) {
-            int t = (ty - row0) * tiles_x + tx;
-            int pos = atomicAdd(&tile_cursor[t], 1);
-            ids[tile_offsets[t] + pos] = g;
+    const int w = box.x1 - box.x0;
+    const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
+    // Four returning atomics are put in flight before the first dependent store: a lane's
+    // round trips overlap instead of adding up.
+    int tx = box.x0, ty = y0;
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+        int t[4], pos[4], off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            t[u] = (k0 + u < cnt) ? (ty - row0) * tiles_x + tx : -1;
+            if (++tx >= box.x1) {
+                tx = box.x0;
+                ++ty;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pos[u] = 0;
+            off[u] = 0;
+            if (t[u] >= 0) {
+                pos[u] = atomicAdd(&tile_cursor[t[u]], 1);
+                off[u] = tile_offsets[t[u]];
+            }
+        }
+        // slot 0 is always live here; dead slots repeat its store so that the four stores
+        // issue back to back without control flow (and the waits it brings) between them
+        const int first = off[0] + pos[0];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ids[t[u] >= 0 ? off[u] + pos[u] : first] = g;
+    }
 }
 
 // ascending in-place bitonic network; elements past n are a virtual +infinity
@@ -403,24 +428,80 @@ __global__ __launch_bounds__(WAVE) void sort_tiles_kernel(const int *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// rasterize_sum forward: one 16x16 workgroup per tile, one pixel per lane; the tile's
-// Gaussians are staged through LDS in batches of 256 and read back as broadcasts.
+// support rectangle shared by the forward and the backward rasterizer
 // ------------------------------------------------------------------------------------------
+
+// Tile-local pixel range [lo,hi] (inclusive) whose sample coordinate o+l lies within h of c.
+__device__ __forceinline__ void axis_range(float c, float o, float h, int lim_lo, int lim_hi,
+                                           int &lo, int &hi)
+{
+    float flo = ceilf(c - o - h), fhi = floorf(c - o + h);
+    flo = fminf(fmaxf(flo, -1.0f), 32.0f);
+    fhi = fminf(fmaxf(fhi, -2.0f), 32.0f);
+    lo = max(lim_lo, (int)flo);
+    hi = min(lim_hi, (int)fhi);
+}
+
+// Pixels of a tile on which a Gaussian can contribute, as inclusive tile-local ranges clipped
+// to [x0,x1] x [y0,y1] (in/out).  A pair contributes only if alpha >= alpha_min, i.e.
+// sigma <= tau = ln(opacity/alpha_min); inside that ellipse |dx| <= sqrt(2 tau c/det) and
+// |dy| <= sqrt(2 tau a/det).  The bound is padded against rounding and trusted only for a
+// well-conditioned positive-definite conic; otherwise the ranges are left as given (every
+// pixel is evaluated).  An empty result has x1 < x0 or y1 < y0.
+__device__ __forceinline__ void support_rect(float gx, float gy, float a, float b, float c,
+                                             float op, float alpha_min, float ox, float oy,
+                                             int &x0, int &x1, int &y0, int &y1)
+{
+    const float det = a * c - b * b;
+    const float ratio = op / alpha_min;
+    if (!(ratio >= 1.0f)) {
+        x1 = x0 - 1;  // opacity below the cut: no pixel can reach alpha_min
+    } else if (a > 0.f && c > 0.f && det > 1.0e-3f * a * c && ratio < 3.0e38f) {
+        const float tau = 1.001f * __logf(ratio) + 1.0e-3f;
+        const float hx = 1.001f * sqrtf(2.0f * tau * c / det) + 1.0e-3f;
+        const float hy = 1.001f * sqrtf(2.0f * tau * a / det) + 1.0e-3f;
+        if (hx < 1.0e6f && hy < 1.0e6f) {
+            axis_range(gx, ox, hx, x0, x1, x0, x1);
+            axis_range(gy, oy, hy, y0, y1, y0, y1);
+        }
+    }
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share one).  This maps the
+// launch index to a tile index so that each XCD works on a contiguous run of tiles: neighbouring
+// tiles share Gaussians (L2 hits on the gathers) and image cache lines.  Bijective for any T.
+__device__ __forceinline__ int xcd_tile(int bid, int T)
+{
+    const int q = T >> 3, r = T & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// ------------------------------------------------------------------------------------------
+// rasterize_sum forward: one 256-lane workgroup per 16x16 tile, one wave per 8x8 quadrant, one
+// pixel per lane.  The tile's Gaussians are staged through LDS in batches of 256; while staging,
+// each entry's support rectangle yields a 4-bit quadrant mask, a ballot turns the masks of 64
+// entries into one 64-bit scalar per wave, and the wave walks only the set bits (scalar bit
+// scan), reading each surviving entry's record from LDS as a broadcast.
+// ------------------------------------------------------------------------------------------
+
+#define LOG2E 1.4426950408889634f
 
 __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     const int *__restrict__ tile_offsets, const int *__restrict__ ids,
     const float *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacity, float bg0, float bg1,
-    float bg2, int H, int W, int tiles_x, int row0, gi2d_conv cv, const DevStatus *status,
-    float *__restrict__ out)
+    float bg2, int H, int W, int tiles_x, int row0, int T, gi2d_conv cv, int cull,
+    const DevStatus *status, float *__restrict__ out)
 {
-    __shared__ float4 s_a[256];  // gx, gy, conic a, conic b
-    __shared__ float4 s_b[256];  // conic c, opacity, colour r, colour g
+    __shared__ float4 s_a[256];  // gx, gy, -0.5*a*log2e, -b*log2e
+    __shared__ float4 s_b[256];  // -0.5*c*log2e, opacity, colour r, colour g
     __shared__ float s_c[256];   // colour b
-    const int tid = threadIdx.x;
-    const int t = blockIdx.x;
+    __shared__ int s_m[256];     // quadrant mask of the entry (bit = 2*qy + qx)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = xcd_tile(blockIdx.x, T);
     const int tx = t % tiles_x, ty = row0 + t / tiles_x;
-    const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
+    const int lx = ((wave & 1) << 3) + (lane & 7), ly = ((wave >> 1) << 3) + (lane >> 3);
+    const int j = tx * GI2D_BLOCK + lx, i = ty * GI2D_BLOCK + ly;
     const bool inside = (i < H) && (j < W);
     const float px = (float)j + cv.pixel_offset, py = (float)i + cv.pixel_offset;
     float r = 0.f, g = 0.f, b = 0.f;
@@ -428,30 +509,52 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
         r = g = b = __builtin_nanf("");
     } else {
         const int beg = tile_offsets[t], end = tile_offsets[t + 1];
+        const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
+        const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
+        const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
+        const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
         for (int base = beg; base < end; base += 256) {
             const int n = min(256, end - base);
             __syncthreads();
+            int mask = 0;
             if (tid < n) {
-                int gid = ids[base + tid];
-                s_a[tid] = make_float4(xys[2 * gid], xys[2 * gid + 1], conics[3 * gid],
-                                       conics[3 * gid + 1]);
-                s_b[tid] = make_float4(conics[3 * gid + 2], opacity[gid], colors[3 * gid],
+                const int gid = ids[base + tid];
+                const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
+                const float ca = conics[3 * gid], cb = conics[3 * gid + 1], cc = conics[3 * gid + 2];
+                const float op = opacity[gid];
+                s_a[tid] = make_float4(gx, gy, (-0.5f * LOG2E) * ca, (-LOG2E) * cb);
+                s_b[tid] = make_float4((-0.5f * LOG2E) * cc, op, colors[3 * gid],
                                        colors[3 * gid + 1]);
                 s_c[tid] = colors[3 * gid + 2];
+                int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
+                if (cull) support_rect(gx, gy, ca, cb, cc, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
+                if (x0 <= x1 && y0 <= y1) {
+                    const int mx = (x0 < 8 ? 1 : 0) | (x1 >= 8 ? 2 : 0);
+                    const int my = (y0 < 8 ? 1 : 0) | (y1 >= 8 ? 2 : 0);
+                    mask = ((my & 1) ? mx : 0) | ((my & 2) ? (mx << 2) : 0);
+                }
             }
+            s_m[tid] = mask;
             __syncthreads();
-            for (int k = 0; k < n; ++k) {
-                const float4 A = s_a[k];
-                const float4 B = s_b[k];
-                const float cb = s_c[k];
-                const float dx = A.x - px, dy = A.y - py;
-                const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
-                const float e = __builtin_amdgcn_exp2f(-sigma * 1.4426950408889634f);
-                const float alpha = fminf(cv.alpha_cap, B.y * e);
-                const float w = (sigma < 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
-                r = r + B.z * w;
-                g = g + B.w * w;
-                b = b + cb * w;
+            for (int c0 = 0; c0 < n; c0 += 64) {
+                unsigned long long bits = __ballot((s_m[c0 + lane] >> wave) & 1);
+                while (bits) {
+                    const int k = c0 + (int)__builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    const float4 A = s_a[k];
+                    const float4 B = s_b[k];
+                    const float cb = s_c[k];
+                    const float dx = A.x - px, dy = A.y - py;
+                    // p = -sigma*log2(e) = (A'dx + B'dy)dx + C'dy*dy
+                    const float q = __builtin_fmaf(A.w, dy, A.z * dx);
+                    const float p = __builtin_fmaf(B.x * dy, dy, q * dx);
+                    const float e = __builtin_amdgcn_exp2f(p);
+                    const float alpha = fminf(cv.alpha_cap, B.y * e);
+                    const float w = (p > 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
+                    r = __builtin_fmaf(B.z, w, r);
+                    g = __builtin_fmaf(B.w, w, g);
+                    b = __builtin_fmaf(cb, w, b);
+                }
             }
         }
         r = r + cv.bg_weight * bg0;
@@ -480,28 +583,17 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
 
 #define PART_STRIDE 9
 
-// Tile-local pixel range [lo,hi] (inclusive) whose sample coordinate o+l lies within h of c.
-__device__ __forceinline__ void axis_range(float c, float o, float h, int lim_lo, int lim_hi,
-                                           int &lo, int &hi)
-{
-    float flo = ceilf(c - o - h), fhi = floorf(c - o + h);
-    flo = fminf(fmaxf(flo, -1.0f), 32.0f);
-    fhi = fminf(fmaxf(fhi, -2.0f), 32.0f);
-    lo = max(lim_lo, (int)flo);
-    hi = min(lim_hi, (int)fhi);
-}
-
 __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     const int *__restrict__ tile_offsets, const int *__restrict__ ids,
     const float *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacity, int H, int W,
-    int tiles_x, int row0, gi2d_conv cv, int cull, const DevStatus *status,
+    int tiles_x, int row0, int T, gi2d_conv cv, int cull, const DevStatus *status,
     const float *__restrict__ v_out, float *__restrict__ partials)
 {
     __shared__ float s_v[3][256];
     if (status->overflow) return;
     const int tid = threadIdx.x;
-    const int t = blockIdx.x;
+    const int t = xcd_tile(blockIdx.x, T);
     const int beg = tile_offsets[t], end = tile_offsets[t + 1];
     if (beg == end) return;
     const int tx = t % tiles_x, ty = row0 + t / tiles_x;
@@ -536,24 +628,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
             const float op = opacity[gid];
             const float cr = colors[3 * gid], cg = colors[3 * gid + 1], cb = colors[3 * gid + 2];
             int x0 = 0, x1 = x_hi, y0 = strip * 4, y1 = min(strip * 4 + 3, y_hi);
-            if (cull) {
-                // alpha >= alpha_min  <=>  sigma <= tau = ln(op/alpha_min); inside that ellipse
-                // |dx| <= sqrt(2 tau c/det), |dy| <= sqrt(2 tau a/det).  Trusted only for a
-                // well-conditioned positive-definite conic, padded against rounding.
-                const float det = a * c - b * b;
-                const float ratio = op / cv.alpha_min;
-                if (!(ratio >= 1.0f)) {
-                    x1 = -1;  // no pixel can reach alpha_min
-                } else if (a > 0.f && c > 0.f && det > 1.0e-3f * a * c && ratio < 3.0e38f) {
-                    const float tau = 1.001f * __logf(ratio) + 1.0e-3f;
-                    const float hx = 1.001f * sqrtf(2.0f * tau * c / det) + 1.0e-3f;
-                    const float hy = 1.001f * sqrtf(2.0f * tau * a / det) + 1.0e-3f;
-                    if (hx < 1.0e6f && hy < 1.0e6f) {
-                        axis_range(gx, ox, hx, 0, x_hi, x0, x1);
-                        axis_range(gy, oy, hy, y0, y1, y0, y1);
-                    }
-                }
-            }
+            if (cull) support_rect(gx, gy, a, b, c, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
             const int w = x1 - x0 + 1, h = y1 - y0 + 1;
             const int cnt = (w > 0 && h > 0) ? w * h : 0;
             int x = x0, y = y0;
@@ -638,6 +713,69 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(
     v_colors[3 * g + 1] = acc[6];
     v_colors[3 * g + 2] = acc[7];
     v_opacity[g] = acc[8];
+}
+
+// ------------------------------------------------------------------------------------------
+// Adan step, fused: one launch over all parameter tensors, one read and one write of each of
+// p, m, n, diff, neg_pre_grad (the reference's default path makes 18 multi-tensor passes).
+// Operation order per element follows /root/reference/optimizer.py:319-362.
+// ------------------------------------------------------------------------------------------
+
+#define ADAN_MAX_TENSORS 8
+
+struct AdanTensors {
+    float *p[ADAN_MAX_TENSORS];
+    float *g[ADAN_MAX_TENSORS];
+    float *m[ADAN_MAX_TENSORS];
+    float *n[ADAN_MAX_TENSORS];
+    float *d[ADAN_MAX_TENSORS];
+    float *prev[ADAN_MAX_TENSORS];
+    long long numel[ADAN_MAX_TENSORS];
+};
+
+struct AdanScalars {
+    float beta1, omb1, beta2, omb2, beta3, omb3;
+    float bc3_sqrt, eps, neg_step, neg_step_diff, decay_mul, decay_div;
+    int no_prox, first_step;
+};
+
+__global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScalars h,
+                                                        const float *__restrict__ clip_dev)
+{
+    const int k = blockIdx.y;
+    float *__restrict__ p = T.p[k];
+    float *__restrict__ gr = T.g[k];
+    float *__restrict__ m = T.m[k];
+    float *__restrict__ n = T.n[k];
+    float *__restrict__ d = T.d[k];
+    float *__restrict__ prev = T.prev[k];
+    const long long numel = T.numel[k];
+    const float clip = clip_dev ? clip_dev[0] : 1.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel;
+         i += (long long)gridDim.x * blockDim.x) {
+        float g = gr[i];
+        if (clip_dev) {
+            g = g * clip;
+            gr[i] = g;  // the reference scales the gradient in place
+        }
+        const float np0 = h.first_step ? -g : prev[i];   // optimizer.py:187-189
+        const float diff = np0 + g;                       // :323
+        const float mi = m[i] * h.beta1 + h.omb1 * g;     // :325-326
+        const float di = d[i] * h.beta2 + h.omb2 * diff;  // :328-330
+        const float u = diff * h.beta2 + g;               // :332-333
+        const float ni = n[i] * h.beta3 + h.omb3 * (u * u);  // :334-338
+        const float denom = sqrtf(ni) / h.bc3_sqrt + h.eps;  // :340-342
+        float pi = p[i];
+        if (h.no_prox) pi = pi * h.decay_mul;             // :348
+        pi = pi + h.neg_step * (mi / denom);              // :349 / :355
+        pi = pi + h.neg_step_diff * (di / denom);         // :350 / :356
+        if (!h.no_prox) pi = pi / h.decay_div;            // :360
+        m[i] = mi;
+        d[i] = di;
+        n[i] = ni;
+        p[i] = pi;
+        prev[i] = -g;                                     // :361-362
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1081,6 +1219,7 @@ int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *co
 {
     int rc = check_raster_args(ws, N, H, W, conv);
     if (rc != GI2D_OK) return rc;
+    if (ws->tiles_x * (ws->bin_row1 - ws->bin_row0) == 0) return GI2D_OK;  // empty band
     if (!out_img || (N > 0 && (!xys || !conics || !colors || !opacity))) return GI2D_E_INVALID;
     if (conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
     DeviceGuard guard(ws->device);
@@ -1095,7 +1234,8 @@ int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *co
     if (T == 0) return GI2D_OK;
     rasterize_sum_fwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
                                                 opacity, bg[0], bg[1], bg[2], H, W, ws->tiles_x,
-                                                ws->bin_row0, *conv, ws->d_status, out_img);
+                                                ws->bin_row0, T, *conv, ws->cull, ws->d_status,
+                                                out_img);
     return launch_status();
 }
 
@@ -1123,7 +1263,7 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (T > 0) {
         rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
-                                                    opacity, H, W, ws->tiles_x, ws->bin_row0,
+                                                    opacity, H, W, ws->tiles_x, ws->bin_row0, T,
                                                     *conv, ws->cull, ws->d_status, v_out,
                                                     ws->d_partials);
         rc = launch_status();
@@ -1134,6 +1274,64 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
                                                       ws->d_status, v_xys, v_conics, v_colors,
                                                       v_opacity);
     return launch_status();
+}
+
+int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
+                   float *const *exp_avg, float *const *exp_avg_sq, float *const *exp_avg_diff,
+                   float *const *neg_pre_grad, const int64_t *numel, const gi2d_adan_hyper *hyper,
+                   const float *clip_dev, void *stream)
+{
+    if (num_tensors < 0 || !hyper || hyper->step < 1) return GI2D_E_INVALID;
+    if (num_tensors == 0) return GI2D_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !exp_avg_diff || !neg_pre_grad || !numel)
+        return GI2D_E_INVALID;
+    const double b1 = hyper->beta1, b2 = hyper->beta2, b3 = hyper->beta3, lr = hyper->lr;
+    const double bc1 = 1.0 - pow(b1, (double)hyper->step);
+    const double bc2 = 1.0 - pow(b2, (double)hyper->step);
+    const double bc3 = 1.0 - pow(b3, (double)hyper->step);
+    AdanScalars h;
+    h.beta1 = (float)b1;
+    h.omb1 = (float)(1.0 - b1);
+    h.beta2 = (float)b2;
+    h.omb2 = (float)(1.0 - b2);
+    h.beta3 = (float)b3;
+    h.omb3 = (float)(1.0 - b3);
+    h.bc3_sqrt = (float)sqrt(bc3);
+    h.eps = (float)hyper->eps;
+    h.neg_step = (float)(-(lr / bc1));
+    h.neg_step_diff = (float)(-(lr * b2 / bc2));
+    h.decay_mul = (float)(1.0 - lr * hyper->weight_decay);
+    h.decay_div = (float)(1.0 + lr * hyper->weight_decay);
+    h.no_prox = hyper->no_prox ? 1 : 0;
+    h.first_step = hyper->step == 1 ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < num_tensors; base += ADAN_MAX_TENSORS) {
+        AdanTensors T;
+        const int cnt = num_tensors - base < ADAN_MAX_TENSORS ? num_tensors - base : ADAN_MAX_TENSORS;
+        long long longest = 0;
+        for (int k = 0; k < ADAN_MAX_TENSORS; ++k) {
+            const int src = base + (k < cnt ? k : 0);
+            if (numel[src] < 0) return GI2D_E_INVALID;
+            if (numel[src] > 0 && (!params[src] || !grads[src] || !exp_avg[src] ||
+                                   !exp_avg_sq[src] || !exp_avg_diff[src] || !neg_pre_grad[src]))
+                return GI2D_E_INVALID;
+            T.p[k] = params[src];
+            T.g[k] = grads[src];
+            T.m[k] = exp_avg[src];
+            T.n[k] = exp_avg_sq[src];
+            T.d[k] = exp_avg_diff[src];
+            T.prev[k] = neg_pre_grad[src];
+            T.numel[k] = k < cnt ? (long long)numel[src] : 0;
+            if (T.numel[k] > longest) longest = T.numel[k];
+        }
+        if (longest == 0) continue;
+        long long blocks = (longest + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        adan_step_kernel<<<dim3((unsigned)blocks, (unsigned)cnt), 256, 0, st>>>(T, h, clip_dev);
+        int rc = launch_status();
+        if (rc != GI2D_OK) return rc;
+    }
+    return GI2D_OK;
 }
 
 }  // extern "C"

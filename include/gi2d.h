@@ -131,6 +131,24 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
                            int H, int W, const gi2d_conv *conv, const float *v_out, float *v_xys,
                            float *v_conics, float *v_colors, float *v_opacity, void *stream);
 
+/* Adan optimizer step for the parameter tensors of the fitted image, the step
+ * that follows the path in every training iteration
+ * (gaussianimage_cholesky.py:120 -> optimizer.py:125-235, update rule
+ * optimizer.py:296-362).  One launch over all tensors.  Host arrays of device
+ * pointers; `step` is the 1-based step count AFTER the increment of
+ * optimizer.py:166-169; step 1 takes neg_pre_grad = -grad (optimizer.py:187).
+ * clip_dev: optional device scalar multiplied into the gradients in place
+ * (the global-norm clip of optimizer.py:133-150), NULL = 1. */
+typedef struct gi2d_adan_hyper {
+    double lr, beta1, beta2, beta3, eps, weight_decay;
+    int no_prox;
+    int step;
+} gi2d_adan_hyper;
+int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
+                   float *const *exp_avg, float *const *exp_avg_sq, float *const *exp_avg_diff,
+                   float *const *neg_pre_grad, const int64_t *numel, const gi2d_adan_hyper *hyper,
+                   const float *clip_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
