@@ -130,6 +130,57 @@ def bench_region(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def bench_model_loops(name, device, steps):
+    """The reference's own two loops on a stand-in of its model (gaussianimage_amd/harness.py),
+    through the drop-in operators: train_iter (forward, L2 loss, backward, PSNR .item(), Adan
+    step, StepLR -- /root/reference/train.py:141-145) and the FPS loop (100 x model() under
+    eval + no_grad, wall clock -- /root/reference/train.py:242-249; synchronised at both ends
+    here)."""
+    from gaussianimage_amd import harness, synth
+    H, W, N, kind, _ = WORKLOADS[name]
+    torch.manual_seed(1)
+    if kind == "cholesky":
+        model = harness.CholeskyImageModel(N, H, W, device)
+    else:
+        model = harness.RSImageModel(N, H, W, device)
+    gt = synth.target_image(H, W).to(device)
+    out = {}
+    model.train()
+    for _ in range(10):
+        model.train_iter(gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, psnr = model.train_iter(gt)
+    torch.cuda.synchronize()
+    out["train_step_ms"] = (time.perf_counter() - t0) / steps * 1e3
+    out["train_step_note"] = ("reference-style train_iter: model forward (3 raster passes for "
+                              "cholesky), mse, backward, .item(), fused Adan, StepLR")
+    out["psnr_after_%d_iters" % (steps + 10)] = psnr
+    model.eval()
+    with torch.no_grad():
+        for _ in range(10):
+            model()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            model()
+        torch.cuda.synchronize()
+        out["reference_fps_loop"] = 100 / (time.perf_counter() - t0)
+    if kind == "cholesky":
+        model.passes = 1
+        model.train()
+        for _ in range(5):
+            model.train_iter(gt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.train_iter(gt)
+        torch.cuda.synchronize()
+        out["train_step_1pass_ms"] = (time.perf_counter() - t0) / steps * 1e3
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +282,7 @@ def main():
         # and transcendental work on cache-resident data, not HBM traffic.
         pairs = I * 256
         ex["pair_evals_per_s"] = pairs / (raster_avg_ms * 1e-3)
+        ex.update(bench_model_loops(args.workload, device, k))
         result["extras"] = ex
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         result["cpu_baseline"] = time_cpu_oracle(args.workload)
