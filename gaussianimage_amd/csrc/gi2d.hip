@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <new>
 
 #include "../../include/gi2d.h"
@@ -17,6 +18,10 @@
 // Workgroup size of the per-Gaussian kernels that issue scattered atomics: one wave, so that
 // the launch spreads over every CU (a CU retires scattered atomics slowly; many CUs do not).
 #define PG_THREADS 64
+// Per-tile counters live one per 128-byte line: device-scope atomics on one line serialise at
+// the memory side, and ~48 Gaussians per tile hammering 32 neighbouring counters of one line
+// made the two atomic passes the slowest kernels of the frame.
+#define CNT_STRIDE 32
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -27,6 +32,7 @@ struct DevStatus {
     int overflow;        // 1: the lists do not fit, later kernels skip their work
     int pad;
     long long total;     // number of (tile, Gaussian) intersections
+    long long generation;
 };
 
 __device__ __forceinline__ int f2i_sat(float v)
@@ -124,7 +130,7 @@ __device__ __forceinline__ void project_tail(int g, float mx, float my, float sx
         const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = box.x0; tx < box.x1; ++tx)
-                atomicAdd(&tile_count[(ty - row0) * tiles_x + tx], 1);
+                atomicAdd(&tile_count[((ty - row0) * tiles_x + tx) * CNT_STRIDE], 1);
     }
 }
 
@@ -266,22 +272,32 @@ __global__ __launch_bounds__(256) void count_tiles_kernel(const float *__restric
     const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
     for (int ty = y0; ty < y1; ++ty)
         for (int tx = box.x0; tx < box.x1; ++tx)
-            atomicAdd(&tile_count[(ty - row0) * tiles_x + tx], 1);
+            atomicAdd(&tile_count[((ty - row0) * tiles_x + tx) * CNT_STRIDE], 1);
 }
 
 // One workgroup: exclusive scan of the per-tile counts into tile_offsets[T+1]; leaves the
 // counters at zero so that the fill kernel can use them as per-tile cursors.
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(int *tile_count, int *tile_offsets, int T,
                                                            long long ids_cap, DevStatus *status,
-                                                           volatile long long *h_status,
                                                            long long generation)
 {
     __shared__ long long wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = (T + 1023) / 1024;
     const int b = min(T, tid * chunk), e = min(T, b + chunk);
+    // up to SCAN_REG counters per lane stay in registers: one round trip to memory, not two
+    constexpr int SCAN_REG = 8;
+    int c[SCAN_REG];
     long long s = 0;
-    for (int i = b; i < e; ++i) s += tile_count[i];
+    if (chunk <= SCAN_REG) {
+#pragma unroll
+        for (int u = 0; u < SCAN_REG; ++u)
+            c[u] = (b + u < e) ? tile_count[(size_t)(b + u) * CNT_STRIDE] : 0;
+#pragma unroll
+        for (int u = 0; u < SCAN_REG; ++u) s += c[u];
+    } else {
+        for (int i = b; i < e; ++i) s += tile_count[(size_t)i * CNT_STRIDE];
+    }
     long long inc = s;
     for (int d = 1; d < 64; d <<= 1) {
         long long o = __shfl_up(inc, d);
@@ -295,21 +311,31 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(int *tile_count, int *
         if (w < wave) wbase += v;
         total += v;
     }
+    const bool over = total > ids_cap || total >= (long long)INT_MAX;
     long long run = wbase + inc - s;
-    for (int i = b; i < e; ++i) {
-        int c = tile_count[i];
-        tile_offsets[i] = (int)(run < (long long)INT_MAX ? run : (long long)INT_MAX);
-        run += c;
-        tile_count[i] = 0;
+    if (chunk <= SCAN_REG) {
+#pragma unroll
+        for (int u = 0; u < SCAN_REG; ++u)
+            if (b + u < e) {
+                tile_offsets[b + u] = (int)(run < (long long)INT_MAX ? run : (long long)INT_MAX);
+                run += c[u];
+                tile_count[(size_t)(b + u) * CNT_STRIDE] = 0;
+            }
+    } else {
+        for (int i = b; i < e; ++i) {
+            int ci = tile_count[(size_t)i * CNT_STRIDE];
+            tile_offsets[i] = (int)(run < (long long)INT_MAX ? run : (long long)INT_MAX);
+            run += ci;
+            tile_count[(size_t)i * CNT_STRIDE] = 0;
+        }
     }
     if (tid == 0) {
-        bool over = total > ids_cap || total >= (long long)INT_MAX;
-        tile_offsets[T] = (int)(total < (long long)INT_MAX ? total : (long long)INT_MAX);
+        // tile_offsets[T] doubles as the overflow sentinel every later kernel reads together
+        // with its own list bounds: -1 = the lists do not fit, skip
+        tile_offsets[T] = over ? -1 : (int)total;
         status->overflow = over ? 1 : 0;
         status->total = total;
-        h_status[0] = total;
-        h_status[1] = generation;
-        if (over) h_status[2] = generation;
+        status->generation = generation;
     }
 }
 
@@ -318,15 +344,25 @@ __global__ __launch_bounds__(256) void fill_tiles_kernel(const float *__restrict
                                                           int tiles_x, int tiles_y, int row0,
                                                           int row1,
                                                           const int *__restrict__ tile_offsets,
-                                                          int *tile_cursor, int *ids,
-                                                          const DevStatus *status)
+                                                          int *tile_cursor, int *ids, int T,
+                                                          const DevStatus *status,
+                                                          volatile long long *h_status)
 {
-    if (status->overflow) return;
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) {
+        // Host-visible copy of the count (pinned memory, read without synchronisation by the
+        // next calls).  Issued first so that the slow host write overlaps the rest of the kernel.
+        const long long total = status->total, gen = status->generation;
+        h_status[0] = total;
+        h_status[1] = gen;
+        if (status->overflow) h_status[2] = gen;
+    }
     if (g >= N) return;
-    int r = radii[g];
+    const int r = radii[g];
+    const float cx = xys[2 * g], cy = xys[2 * g + 1];
+    if (tile_offsets[T] < 0) return;  // overflow
     if (r <= 0) return;
-    TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
+    TileBox box = tile_box(cx, cy, (float)r, tiles_x, tiles_y);
     const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
     const int w = box.x1 - box.x0;
     const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
@@ -348,7 +384,7 @@ __global__ __launch_bounds__(256) void fill_tiles_kernel(const float *__restrict
             pos[u] = 0;
             off[u] = 0;
             if (t[u] >= 0) {
-                pos[u] = atomicAdd(&tile_cursor[t[u]], 1);
+                pos[u] = atomicAdd(&tile_cursor[(size_t)t[u] * CNT_STRIDE], 1);
                 off[u] = tile_offsets[t[u]];
             }
         }
@@ -399,32 +435,61 @@ __device__ __forceinline__ void bitonic_sort(P a, int n, int lane, int nthreads)
 
 #define SORT_LDS_MAX 4096
 
+// Rank sort of up to 64*R distinct ints held R per lane: every value is broadcast once with
+// v_readlane and each lane counts how many are smaller than its own.  No LDS, no barrier.
+template <int R>
+__device__ __forceinline__ void rank_sort_regs(int *ids, int beg, int n, int lane)
+{
+    int v[R], rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int idx = r * WAVE + lane;
+        v[r] = idx < n ? ids[beg + idx] : INT_MAX;
+        rank[r] = 0;
+    }
+#pragma unroll
+    for (int r2 = 0; r2 < R; ++r2) {
+        const int lim = __builtin_amdgcn_readfirstlane(min(WAVE, n - r2 * WAVE));
+        for (int k = 0; k < lim; ++k) {
+            const int sv = __builtin_amdgcn_readlane(v[r2], k);
+#pragma unroll
+            for (int r = 0; r < R; ++r) rank[r] += (sv < v[r]) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (r * WAVE + lane < n) ids[beg + rank[r]] = v[r];
+}
+
 // One wave per tile: puts the tile's Gaussian ids in ascending order (the fill order depends
-// on atomic arrival) and returns the tile's cursor to zero for the next binning.
+// on atomic arrival) and returns the tile's cursor to zero for the next binning.  The launch
+// lasts as long as its slowest tile, so lists up to 256 entries stay on the register path;
+// longer ones use a bitonic network in LDS, and beyond the LDS budget in place in memory.
 __global__ __launch_bounds__(WAVE) void sort_tiles_kernel(const int *__restrict__ tile_offsets,
-                                                          int *ids, int *tile_cursor,
-                                                          const DevStatus *status)
+                                                          int *ids, int *tile_cursor, int T)
 {
     __shared__ int s_ids[SORT_LDS_MAX];
     const int t = blockIdx.x, lane = threadIdx.x;
-    if (lane == 0) tile_cursor[t] = 0;
-    if (status->overflow) return;
-    const int beg = tile_offsets[t], n = tile_offsets[t + 1] - beg;
-    if (n <= 1) return;
-    if (n <= WAVE) {
-        int v = lane < n ? ids[beg + lane] : INT_MAX;
-        int rank = 0;
-        const int nu = __builtin_amdgcn_readfirstlane(n);
-        for (int k = 0; k < nu; ++k) rank += (__builtin_amdgcn_readlane(v, k) < v) ? 1 : 0;
-        if (lane < n) ids[beg + rank] = v;
-    } else if (n <= SORT_LDS_MAX) {
-        for (int i = lane; i < n; i += WAVE) s_ids[i] = ids[beg + i];
-        __syncthreads();
-        bitonic_sort(s_ids, n, lane, WAVE);
-        for (int i = lane; i < n; i += WAVE) ids[beg + i] = s_ids[i];
-    } else {
-        bitonic_sort(ids + beg, n, lane, WAVE);
+    // the three list words are independent loads: one round trip
+    const int beg = tile_offsets[t], fin = tile_offsets[t + 1], sentinel = tile_offsets[T];
+    const int n = sentinel < 0 ? 0 : fin - beg;
+    if (n > 1) {
+        if (n <= WAVE) {
+            rank_sort_regs<1>(ids, beg, n, lane);
+        } else if (n <= 2 * WAVE) {
+            rank_sort_regs<2>(ids, beg, n, lane);
+        } else if (n <= 4 * WAVE) {
+            rank_sort_regs<4>(ids, beg, n, lane);
+        } else if (n <= SORT_LDS_MAX) {
+            for (int i = lane; i < n; i += WAVE) s_ids[i] = ids[beg + i];
+            __syncthreads();
+            bitonic_sort(s_ids, n, lane, WAVE);
+            for (int i = lane; i < n; i += WAVE) ids[beg + i] = s_ids[i];
+        } else {
+            bitonic_sort(ids + beg, n, lane, WAVE);
+        }
     }
+    if (lane == 0) tile_cursor[(size_t)t * CNT_STRIDE] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -491,7 +556,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     const float *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacity, float bg0, float bg1,
     float bg2, int H, int W, int tiles_x, int row0, int T, gi2d_conv cv, int cull,
-    const DevStatus *status, float *__restrict__ out)
+    float *__restrict__ out)
 {
     __shared__ float4 s_a[256];  // gx, gy, -0.5*a*log2e, -b*log2e
     __shared__ float4 s_b[256];  // -0.5*c*log2e, opacity, colour r, colour g
@@ -505,10 +570,11 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     const bool inside = (i < H) && (j < W);
     const float px = (float)j + cv.pixel_offset, py = (float)i + cv.pixel_offset;
     float r = 0.f, g = 0.f, b = 0.f;
-    if (status->overflow) {
-        r = g = b = __builtin_nanf("");
+    // list bounds and the overflow sentinel: three independent loads, one round trip
+    const int beg = tile_offsets[t], end = tile_offsets[t + 1], sentinel = tile_offsets[T];
+    if (sentinel < 0) {
+        r = g = b = __builtin_nanf("");  // the lists did not fit: never a silently wrong image
     } else {
-        const int beg = tile_offsets[t], end = tile_offsets[t + 1];
         const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
         const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
         const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
@@ -582,100 +648,121 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
 // ------------------------------------------------------------------------------------------
 
 #define PART_STRIDE 9
+#define SLOT_TAB 4  // slots per Gaussian remembered by pass 1 (tile boxes are mostly <= 2x2)
 
 __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     const int *__restrict__ tile_offsets, const int *__restrict__ ids,
-    const float *__restrict__ xys, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacity, int H, int W,
-    int tiles_x, int row0, int T, gi2d_conv cv, int cull, const DevStatus *status,
-    const float *__restrict__ v_out, float *__restrict__ partials)
+    const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
+    int T, gi2d_conv cv, int cull, const float *__restrict__ v_out,
+    float *__restrict__ partials, int *__restrict__ slot_tab)
 {
-    __shared__ float s_v[3][256];
-    if (status->overflow) return;
+    __shared__ float4 s_v[256];
     const int tid = threadIdx.x;
     const int t = xcd_tile(blockIdx.x, T);
-    const int beg = tile_offsets[t], end = tile_offsets[t + 1];
-    if (beg == end) return;
+    const int beg = tile_offsets[t], end = tile_offsets[t + 1], sentinel = tile_offsets[T];
+    if (sentinel < 0 || beg == end) return;
     const int tx = t % tiles_x, ty = row0 + t / tiles_x;
     {
         const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < H && j < W) {
             const float *p = v_out + 3 * ((size_t)(i - row0 * GI2D_BLOCK) * W + j);
-            v0 = p[0];
-            v1 = p[1];
-            v2 = p[2];
+            v.x = p[0];
+            v.y = p[1];
+            v.z = p[2];
         }
-        s_v[0][tid] = v0;
-        s_v[1][tid] = v1;
-        s_v[2][tid] = v2;
+        s_v[tid] = v;
     }
     __syncthreads();
     const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
     const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
     const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
     const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
-    const int strip = tid & 3;
+    const int q = tid & 3;
     for (int base = beg; base < end; base += 64) {
         const int e = base + (tid >> 2);
         float acc[PART_STRIDE];
 #pragma unroll
         for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
+        int gid = 0, rad = 0;
+        float gx = 0.f, gy = 0.f;
         if (e < end) {
-            const int gid = ids[e];
-            const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
+            gid = ids[e];
+            gx = xys[2 * gid];
+            gy = xys[2 * gid + 1];
+            rad = radii[gid];
             const float a = conics[3 * gid], b = conics[3 * gid + 1], c = conics[3 * gid + 2];
             const float op = opacity[gid];
             const float cr = colors[3 * gid], cg = colors[3 * gid + 1], cb = colors[3 * gid + 2];
-            int x0 = 0, x1 = x_hi, y0 = strip * 4, y1 = min(strip * 4 + 3, y_hi);
+            int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
             if (cull) support_rect(gx, gy, a, b, c, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
             const int w = x1 - x0 + 1, h = y1 - y0 + 1;
             const int cnt = (w > 0 && h > 0) ? w * h : 0;
-            int x = x0, y = y0;
-            for (int k = 0; k < cnt; ++k) {
+            // the four lanes of the quad take the rectangle's pixels round-robin
+            const int step_y = cnt ? 4 / w : 0, step_x = cnt ? 4 - step_y * w : 0;
+            int x = x0 + q, y = y0;
+            while (cnt && x > x1) {
+                x -= w;
+                ++y;
+            }
+            const float pa = (-0.5f * LOG2E) * a, pb = (-LOG2E) * b, pc = (-0.5f * LOG2E) * c;
+            for (int k = q; k < cnt; k += 4) {
                 const float dx = gx - (ox + (float)x), dy = gy - (oy + (float)y);
-                const float sigma = 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
-                const float ex = __builtin_amdgcn_exp2f(-sigma * 1.4426950408889634f);
+                const float p = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
+                const float ex = __builtin_amdgcn_exp2f(p);
                 const float oe = op * ex;
                 const float alpha = fminf(cv.alpha_cap, oe);
-                if (!(sigma < 0.f || alpha < cv.alpha_min)) {
-                    const int p = y * GI2D_BLOCK + x;
-                    const float v0 = s_v[0][p], v1 = s_v[1][p], v2 = s_v[2][p];
-                    acc[5] += alpha * v0;
-                    acc[6] += alpha * v1;
-                    acc[7] += alpha * v2;
-                    if (!(oe > cv.alpha_cap)) {
-                        const float v_alpha = cr * v0 + cg * v1 + cb * v2;
-                        const float v_sigma = -oe * v_alpha;
-                        acc[8] += ex * v_alpha;
-                        acc[0] += v_sigma * (a * dx + b * dy);
-                        acc[1] += v_sigma * (b * dx + c * dy);
-                        acc[2] += v_sigma * (0.5f * dx * dx);
-                        acc[3] += v_sigma * (dx * dy);
-                        acc[4] += v_sigma * (0.5f * dy * dy);
-                    }
-                }
-                if (++x > x1) {
-                    x = x0;
+                const bool on = !(p > 0.f || alpha < cv.alpha_min);
+                const float4 v = s_v[y * GI2D_BLOCK + x];
+                const float am = on ? alpha : 0.f;
+                acc[5] = __builtin_fmaf(am, v.x, acc[5]);
+                acc[6] = __builtin_fmaf(am, v.y, acc[6]);
+                acc[7] = __builtin_fmaf(am, v.z, acc[7]);
+                const float v_alpha = __builtin_fmaf(cb, v.z, __builtin_fmaf(cg, v.y, cr * v.x));
+                const bool live = on && !(oe > cv.alpha_cap);  // a capped alpha is a constant
+                const float va = live ? v_alpha : 0.f;
+                const float vs = -oe * va;
+                acc[8] = __builtin_fmaf(ex, va, acc[8]);
+                acc[0] = __builtin_fmaf(vs, __builtin_fmaf(b, dy, a * dx), acc[0]);
+                acc[1] = __builtin_fmaf(vs, __builtin_fmaf(c, dy, b * dx), acc[1]);
+                const float hx = vs * dx, hy = vs * dy;
+                acc[2] = __builtin_fmaf(0.5f * hx, dx, acc[2]);
+                acc[3] = __builtin_fmaf(hx, dy, acc[3]);
+                acc[4] = __builtin_fmaf(0.5f * hy, dy, acc[4]);
+                x += step_x;
+                y += step_y;
+                if (x > x1) {
+                    x -= w;
                     ++y;
                 }
             }
         }
 #pragma unroll
         for (int k = 0; k < PART_STRIDE; ++k) acc[k] = quad_sum(acc[k]);
-        if (e < end && strip == 0) {
+        if (e < end && q == 0) {
             float *dst = partials + (size_t)e * PART_STRIDE;
 #pragma unroll
             for (int k = 0; k < PART_STRIDE; ++k) dst[k] = acc[k];
+            // where the second pass finds this slot without searching: index of this tile in
+            // the Gaussian's own (band-clipped) tile box, first SLOT_TAB tiles only
+            if (rad > 0) {
+                TileBox box = tile_box(gx, gy, (float)rad, tiles_x, tiles_y);
+                const int by0 = max(box.y0, row0);
+                const int kb = (ty - by0) * (box.x1 - box.x0) + (tx - box.x0);
+                if (kb >= 0 && kb < SLOT_TAB) slot_tab[(size_t)gid * SLOT_TAB + kb] = e;
+            }
         }
     }
 }
 
 __global__ __launch_bounds__(256) void gather_grads_kernel(
     const float *__restrict__ xys, const int *__restrict__ radii, int N, int tiles_x, int tiles_y,
-    int row0, int row1, const int *__restrict__ tile_offsets, const int *__restrict__ ids,
-    const float *__restrict__ partials, const DevStatus *status, float *__restrict__ v_xy,
-    float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity)
+    int row0, int row1, int T, const int *__restrict__ tile_offsets, const int *__restrict__ ids,
+    const float *__restrict__ partials, const int *__restrict__ slot_tab,
+    float *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_colors,
+    float *__restrict__ v_opacity)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
@@ -683,26 +770,48 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(
 #pragma unroll
     for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
     const int r = radii[g];
-    if (r > 0 && !status->overflow) {
-        TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
+    const float cx = xys[2 * g], cy = xys[2 * g + 1];
+    const int4 tab = *reinterpret_cast<const int4 *>(slot_tab + (size_t)g * SLOT_TAB);
+    const int sentinel = tile_offsets[T];
+    if (r > 0 && sentinel >= 0) {
+        TileBox box = tile_box(cx, cy, (float)r, tiles_x, tiles_y);
         const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
-        for (int ty = y0; ty < y1; ++ty)
-            for (int tx = box.x0; tx < box.x1; ++tx) {
-                const int t = (ty - row0) * tiles_x + tx;
-                int lo = tile_offsets[t], hi = tile_offsets[t + 1];
-                while (lo < hi) {  // first slot with id >= g
-                    int mid = (lo + hi) >> 1;
-                    if (ids[mid] < g)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                if (lo < tile_offsets[t + 1] && ids[lo] == g) {
-                    const float *src = partials + (size_t)lo * PART_STRIDE;
+        const int w = box.x1 - box.x0;
+        const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
+        // the first SLOT_TAB tiles: slots remembered by pass 1, loads independent of each other
+        {
+            const int slots[SLOT_TAB] = {tab.x, tab.y, tab.z, tab.w};
+            float part[SLOT_TAB][PART_STRIDE];
 #pragma unroll
-                    for (int k = 0; k < PART_STRIDE; ++k) acc[k] += src[k];
-                }
+            for (int k = 0; k < SLOT_TAB; ++k) {
+                const float *src = partials + (size_t)(k < cnt ? slots[k] : 0) * PART_STRIDE;
+#pragma unroll
+                for (int u = 0; u < PART_STRIDE; ++u) part[k][u] = (k < cnt) ? src[u] : 0.f;
             }
+#pragma unroll
+            for (int k = 0; k < SLOT_TAB; ++k)
+#pragma unroll
+                for (int u = 0; u < PART_STRIDE; ++u) acc[u] += part[k][u];
+        }
+        // larger boxes: the rest by binary search (tile lists ascend in Gaussian id)
+        for (int k = SLOT_TAB; k < cnt; ++k) {
+            const int ty = y0 + k / w, tx = box.x0 + k % w;
+            const int t = (ty - row0) * tiles_x + tx;
+            int lo = tile_offsets[t], hi = tile_offsets[t + 1];
+            const int fin = hi;
+            while (lo < hi) {  // first slot with id >= g
+                int mid = (lo + hi) >> 1;
+                if (ids[mid] < g)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (lo < fin && ids[lo] == g) {
+                const float *src = partials + (size_t)lo * PART_STRIDE;
+#pragma unroll
+                for (int u = 0; u < PART_STRIDE; ++u) acc[u] += src[u];
+            }
+        }
     }
     v_xy[2 * g] = acc[0];
     v_xy[2 * g + 1] = acc[1];
@@ -791,6 +900,8 @@ struct gi2d_workspace {
     int *d_ids = nullptr;
     int64_t part_cap = 0;
     float *d_partials = nullptr;
+    int64_t slot_cap = 0;
+    int *d_slot_tab = nullptr;  // [n][SLOT_TAB] slot of a Gaussian in its first tiles (backward)
     DevStatus *d_status = nullptr;
     long long *h_status = nullptr;   // pinned: [0] total, [1] generation, [2] overflow generation
     long long *h_status_dev = nullptr;
@@ -897,6 +1008,7 @@ int gi2d_workspace_destroy(gi2d_workspace *ws)
     if (ws->d_offsets) (void)hipFree(ws->d_offsets);
     if (ws->d_ids) (void)hipFree(ws->d_ids);
     if (ws->d_partials) (void)hipFree(ws->d_partials);
+    if (ws->d_slot_tab) (void)hipFree(ws->d_slot_tab);
     if (ws->d_status) (void)hipFree(ws->d_status);
     if (ws->h_status) (void)hipHostFree(ws->h_status);
     delete ws;
@@ -912,9 +1024,9 @@ static int ensure_tiles(gi2d_workspace *ws, int T)
     if (ws->d_offsets) (void)hipFree(ws->d_offsets);
     ws->d_count = ws->d_offsets = nullptr;
     ws->tiles_cap = 0;
-    HIP_TRY(hipMalloc(&ws->d_count, sizeof(int) * (size_t)T));
+    HIP_TRY(hipMalloc(&ws->d_count, sizeof(int) * CNT_STRIDE * (size_t)T));
     HIP_TRY(hipMalloc(&ws->d_offsets, sizeof(int) * ((size_t)T + 1)));
-    HIP_TRY(hipMemset(ws->d_count, 0, sizeof(int) * (size_t)T));
+    HIP_TRY(hipMemset(ws->d_count, 0, sizeof(int) * CNT_STRIDE * (size_t)T));
     HIP_TRY(hipMemset(ws->d_offsets, 0, sizeof(int) * ((size_t)T + 1)));
     ws->tiles_cap = T;
     ws->counters_dirty = false;
@@ -994,7 +1106,7 @@ static int begin_fused_count(gi2d_workspace *ws, int N, int tiles_x, int tiles_y
     int rc = ensure_tiles(ws, max(1, (r1 - r0) * tiles_x));
     if (rc != GI2D_OK) return rc;
     if (ws->counters_dirty || ws->counted) {
-        int T = ws->tiles_cap;
+        int T = ws->tiles_cap * CNT_STRIDE;
         zero_ints_kernel<<<cdiv(T, 256), 256, 0, st>>>(ws->d_count, T);
         rc = launch_status();
         if (rc != GI2D_OK) return rc;
@@ -1113,7 +1225,8 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
         int rc = ensure_tiles(ws, max(1, T));
         if (rc != GI2D_OK) return rc;
         if (ws->counters_dirty || ws->counted) {
-            zero_ints_kernel<<<cdiv(ws->tiles_cap, 256), 256, 0, st>>>(ws->d_count, ws->tiles_cap);
+            zero_ints_kernel<<<cdiv(ws->tiles_cap * CNT_STRIDE, 256), 256, 0, st>>>(
+                ws->d_count, ws->tiles_cap * CNT_STRIDE);
             rc = launch_status();
             if (rc != GI2D_OK) return rc;
         }
@@ -1150,14 +1263,16 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     scan_tiles_kernel<<<1, 1024, 0, st>>>(ws->d_count, ws->d_offsets, T,
                                           sync && !nogrow ? (long long)INT_MAX - 1
                                                           : (long long)ws->ids_cap,
-                                          ws->d_status, ws->h_status_dev, ws->generation);
+                                          ws->d_status, ws->generation);
     int rc = launch_status();
     if (rc != GI2D_OK) return rc;
     ws->counters_dirty = false;  // the scan left the counters at zero
 
     if (sync) {
+        DevStatus hs;
+        HIP_TRY(hipMemcpyAsync(&hs, ws->d_status, sizeof(hs), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        int64_t total = ws->h_status[0];
+        int64_t total = hs.total;
         if (total > ws->ids_cap) {
             if (nogrow) {
                 ws->overflow_ack = ws->generation;  // reported here, not again on the next call
@@ -1167,14 +1282,17 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
             if (rc != GI2D_OK) return rc;
         }
     }
-    if (N > 0 && T > 0) {
+    {
+        // always launched: its first lane also publishes the count to the host
         ws->counters_dirty = true;
-        fill_tiles_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(xys, radii, N, tiles_x, tiles_y, r0, r1,
-                                                       ws->d_offsets, ws->d_count, ws->d_ids,
-                                                       ws->d_status);
+        fill_tiles_kernel<<<max(1, cdiv(N, PG_THREADS)), PG_THREADS, 0, st>>>(
+            xys, radii, N, tiles_x, tiles_y, r0, r1, ws->d_offsets, ws->d_count, ws->d_ids, T,
+            ws->d_status, ws->h_status_dev);
         rc = launch_status();
         if (rc != GI2D_OK) return rc;
-        sort_tiles_kernel<<<T, WAVE, 0, st>>>(ws->d_offsets, ws->d_ids, ws->d_count, ws->d_status);
+    }
+    if (T > 0) {
+        sort_tiles_kernel<<<T, WAVE, 0, st>>>(ws->d_offsets, ws->d_ids, ws->d_count, T);
         rc = launch_status();
         if (rc != GI2D_OK) return rc;
         ws->counters_dirty = false;  // the sort returned every cursor to zero
@@ -1234,8 +1352,7 @@ int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *co
     if (T == 0) return GI2D_OK;
     rasterize_sum_fwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
                                                 opacity, bg[0], bg[1], bg[2], H, W, ws->tiles_x,
-                                                ws->bin_row0, T, *conv, ws->cull, ws->d_status,
-                                                out_img);
+                                                ws->bin_row0, T, *conv, ws->cull, out_img);
     return launch_status();
 }
 
@@ -1247,8 +1364,9 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
     int rc = check_raster_args(ws, N, H, W, conv);
     if (rc != GI2D_OK) return rc;
     if (N == 0) return GI2D_OK;
-    if (!xys || !radii || !conics || !colors || !opacity || !v_out || !v_xys || !v_conics ||
-        !v_colors || !v_opacity)
+    const bool empty_band = ws->tiles_x * (ws->bin_row1 - ws->bin_row0) == 0;
+    if (!xys || !radii || !conics || !colors || !opacity || (!v_out && !empty_band) || !v_xys ||
+        !v_conics || !v_colors || !v_opacity)
         return GI2D_E_INVALID;
     DeviceGuard guard(ws->device);
     hipStream_t st = (hipStream_t)stream;
@@ -1260,19 +1378,27 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
         HIP_TRY(hipMalloc(&ws->d_partials, sizeof(float) * PART_STRIDE * (size_t)ws->ids_cap));
         ws->part_cap = ws->ids_cap;
     }
+    if (ws->slot_cap < N) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (ws->d_slot_tab) (void)hipFree(ws->d_slot_tab);
+        ws->d_slot_tab = nullptr;
+        ws->slot_cap = 0;
+        HIP_TRY(hipMalloc(&ws->d_slot_tab, sizeof(int) * SLOT_TAB * (size_t)N));
+        HIP_TRY(hipMemset(ws->d_slot_tab, 0, sizeof(int) * SLOT_TAB * (size_t)N));
+        ws->slot_cap = N;
+    }
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (T > 0) {
-        rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
-                                                    opacity, H, W, ws->tiles_x, ws->bin_row0, T,
-                                                    *conv, ws->cull, ws->d_status, v_out,
-                                                    ws->d_partials);
+        rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(
+            ws->d_offsets, ws->d_ids, xys, radii, conics, colors, opacity, H, W, ws->tiles_x,
+            ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull, v_out, ws->d_partials,
+            ws->d_slot_tab);
         rc = launch_status();
         if (rc != GI2D_OK) return rc;
     }
-    gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(xys, radii, N, ws->tiles_x, ws->tiles_y,
-                                                      ws->bin_row0, ws->bin_row1, ws->d_offsets, ws->d_ids, ws->d_partials,
-                                                      ws->d_status, v_xys, v_conics, v_colors,
-                                                      v_opacity);
+    gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(
+        xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, ws->d_offsets,
+        ws->d_ids, ws->d_partials, ws->d_slot_tab, v_xys, v_conics, v_colors, v_opacity);
     return launch_status();
 }
 

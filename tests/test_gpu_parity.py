@@ -145,7 +145,7 @@ def test_rasterize_backward(ops, oracle, H, W, N, seed, fp):
 
 
 def test_backward_culling_changes_nothing(ops, oracle):
-    """The support-rectangle culling of the backward is exact: same bits with it off."""
+    """The support-rectangle culling (forward and backward) drops no contributing pixel."""
     H, W, N = 80, 96, 800
     means, L, col, op, proj, ws = _project_and_bin(ops, oracle, H, W, N, 4, 2.5)
     op = (0.05 + 0.95 * torch.rand(N, 1, generator=torch.Generator().manual_seed(0))).to(DEV)
@@ -161,10 +161,14 @@ def test_backward_culling_changes_nothing(ops, oracle):
         img = ops.rasterize_gaussians_sum(leaves[0], depths, radii, leaves[1], nth, leaves[2],
                                           leaves[3], H, W, 16, 16)
         (img * v_out).sum().backward()
-        grads.append([_np(l.grad) for l in leaves])
+        grads.append([_np(l.grad) for l in leaves] + [_np(img)])
     ws.set_cull(True)
+    # forward: culled entries contribute exactly zero, the order of the rest is unchanged
+    assert np.array_equal(grads[0].pop(), grads[1].pop())
+    # the culled walk visits the same contributing pixels in another order: equal up to fp32
+    # re-association, far inside the gradient tolerance
     for a, b in zip(*grads):
-        assert np.array_equal(a, b)
+        assert _maxrel(a, b) <= 2e-6
 
 
 @pytest.mark.parametrize("N,seed", [(64, 0), (3000, 1)])
