@@ -98,21 +98,20 @@ def time_cpu_oracle(name, budget_s=12.0):
 
 
 def bench_forward(pipe, inputs, steps, warmup, sync_all):
+    """K forward frames, one C call each (gi2d_render_*_fwd).  The rasterize launch of every
+    timed frame is bracketed by HIP events recorded inside that call on the launch stream."""
     means, cov_a, cov_b, col, op = inputs
-    for _ in range(warmup):
-        pipe.forward(means, cov_a, cov_b, col, op)
-    # raster-kernel timing: HIP events on the launch stream around that call only
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(steps)]
+    for a, b in ev:  # give every event its handle outside the timed region
+        a.record()
+        b.record()
+    for _ in range(warmup):
+        pipe.forward(means, cov_a, cov_b, col, op)
     sync_all()
     t0 = time.perf_counter()
     for k in range(steps):
-        pipe._set_rows()
-        pipe.project(means, cov_a, cov_b)
-        pipe.bin()
-        ev[k][0].record()
-        pipe.rasterize(col, op)
-        ev[k][1].record()
+        pipe.forward(means, cov_a, cov_b, col, op, events=ev[k])
     sync_all()
     el = time.perf_counter() - t0
     raster_ms = sorted(a.elapsed_time(b) for a, b in ev)
@@ -199,11 +198,18 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run "
                              "(--nproc-per-node N)")
     distributed = world > 1
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        # GI2D_BENCH_BACKEND=gloo rehearses the multi-rank path where RCCL cannot run (e.g. two
+        # ranks on one GPU); collectives then go through host memory
+        backend = os.environ.get("GI2D_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -222,7 +228,8 @@ def main():
 
     el, raster_ms = bench_forward(pipe, inputs, args.steps, args.warmup, sync_all)
     if distributed:
-        t = torch.tensor([el], dtype=torch.float64, device=device)
+        t = torch.tensor([el], dtype=torch.float64,
+                         device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     ms_per_step = el / args.steps * 1e3

@@ -67,6 +67,10 @@ SIGNATURES = {
     "gi2d_bin_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gi2d_copy_bins": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "gi2d_rasterize_sum_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp]),
+    "gi2d_render_cholesky_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gi2d_render_rs_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_adan_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(AdanHyper), _vp,
                             _vp]),
     "gi2d_rasterize_sum_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,

@@ -1,14 +1,25 @@
 // gi2d.hip -- MI355X (gfx950, wave64) kernels and C ABI of the accumulated-summation
-// 2D Gaussian rasterizer: projection, tile binning, rasterize_sum forward/backward.
+// 2D Gaussian rasterizer: projection, tile binning, rasterize_sum forward/backward, Adan step.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see build.py).
 // -ffp-contract=off is part of the contract: the projection's integer outputs (radii, tile
 // boxes) must not depend on the compiler's choice of fused multiply-adds.  Where a fused
 // multiply-add is wanted in a hot loop it is written explicitly with __builtin_fmaf.
+//
+// Frame pipeline (forward): TWO launches in steady state.
+//   1. project_*_fwd_kernel  -- per Gaussian: conic, radius, tile box, the API outputs, and for
+//      every tile of the box one returning atomic on the tile's counter followed by a store of
+//      the Gaussian id into the tile's segment (fixed capacity C ids per tile).
+//   2. rasterize_sum_fwd_kernel<FINALIZE> -- per tile: sorts its segment (ids arrive in atomic
+//      order; ascending order makes runs reproducible and lets the backward search lists),
+//      publishes the list length, returns the counter to zero, then rasterises.
+// Every launch costs ~2 us plus ~1-1.5 us per dependent memory round trip on this part, and a
+// 768x512 frame with 30k Gaussians is only a few us of arithmetic, so the design minimises
+// launches and dependent rounds rather than bytes.
 #include <hip/hip_runtime.h>
-#include <stdint.h>
 #include <limits.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <new>
 
@@ -16,23 +27,25 @@
 
 #define WAVE 64
 // Workgroup size of the per-Gaussian kernels that issue scattered atomics: one wave, so that
-// the launch spreads over every CU (a CU retires scattered atomics slowly; many CUs do not).
+// the launch spreads over every CU.
 #define PG_THREADS 64
 // Per-tile counters live one per 128-byte line: device-scope atomics on one line serialise at
 // the memory side, and ~48 Gaussians per tile hammering 32 neighbouring counters of one line
-// made the two atomic passes the slowest kernels of the frame.
+// made the atomic pass three times slower.
 #define CNT_STRIDE 32
+#define LOG2E 1.4426950408889634f
+#define PART_STRIDE 9  // backward partial sums per (tile, Gaussian): v_xy 2, v_conic 3, v_rgb 3, v_op 1
+#define SLOT_TAB 4     // slots per Gaussian remembered by backward pass 1 (boxes are mostly <= 2x2)
 
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
 
-// status words written by the scan kernel and read by everything after it
+// device-side status of a workspace
 struct DevStatus {
-    int overflow;        // 1: the lists do not fit, later kernels skip their work
+    int max_count;            // largest per-tile count seen so far (monotone; capacity policy)
     int pad;
-    long long total;     // number of (tile, Gaussian) intersections
-    long long generation;
+    long long overflow_gen;   // generation of the last frame in which a segment overflowed
 };
 
 __device__ __forceinline__ int f2i_sat(float v)
@@ -96,14 +109,57 @@ __device__ __forceinline__ float quad_sum(float v)
 }
 
 // ------------------------------------------------------------------------------------------
-// projection (one lane per Gaussian)
+// projection and tile binning (one lane per Gaussian)
 // ------------------------------------------------------------------------------------------
+
+// Enters Gaussian g in the segment of every tile of its box (clipped to the band's tile rows
+// [row0,row1)).  Four returning atomics are put in flight before the first dependent store, so
+// a lane's round trips overlap instead of adding up.  Ids beyond a segment's capacity are
+// dropped; the counter keeps counting, which is how the overflow is noticed.
+__device__ __forceinline__ void emit_tiles(int g, const TileBox &box, int row0, int row1,
+                                           int tiles_x, int *tile_count, int *seg, int C)
+{
+    const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
+    const int w = box.x1 - box.x0;
+    const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
+    int tx = box.x0, ty = y0;
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+        int t[4], pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            t[u] = (k0 + u < cnt) ? (ty - row0) * tiles_x + tx : -1;
+            if (++tx >= box.x1) {
+                tx = box.x0;
+                ++ty;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pos[u] = C;
+            if (t[u] >= 0) pos[u] = atomicAdd(&tile_count[(size_t)t[u] * CNT_STRIDE], 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pos[u] < C) seg[(size_t)t[u] * C + pos[u]] = g;
+    }
+}
+
+// At most one lane per launch: copies the device status to pinned host memory, where the next
+// calls read it without synchronising.  Issued first so that the slow host write overlaps the
+// rest of the kernel.
+__device__ __forceinline__ void publish_status(const DevStatus *status, volatile long long *h,
+                                               long long generation)
+{
+    h[0] = status->max_count;
+    h[2] = status->overflow_gen;
+    h[1] = generation;
+}
 
 __device__ __forceinline__ void project_tail(int g, float mx, float my, float sxx, float sxy,
                                              float syy, int H, int W, int tiles_x, int tiles_y,
                                              float center_bias, float *xys, float *depths,
                                              int *radii, float *conics, int *num_tiles_hit,
-                                             int *tile_count, int row0, int row1)
+                                             int *tile_count, int *seg, int C, int row0, int row1)
 {
     float ca = 0.f, cb = 0.f, cc = 0.f, radius = 0.f, cx = 0.f, cy = 0.f;
     int irad = 0, area = 0;
@@ -126,28 +182,27 @@ __device__ __forceinline__ void project_tail(int g, float mx, float my, float sx
     conics[3 * g + 1] = cb;
     conics[3 * g + 2] = cc;
     num_tiles_hit[g] = area;
-    if (tile_count != nullptr && irad > 0 && area > 0) {
-        const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
-        for (int ty = y0; ty < y1; ++ty)
-            for (int tx = box.x0; tx < box.x1; ++tx)
-                atomicAdd(&tile_count[((ty - row0) * tiles_x + tx) * CNT_STRIDE], 1);
-    }
+    if (tile_count != nullptr && irad > 0 && area > 0)
+        emit_tiles(g, box, row0, row1, tiles_x, tile_count, seg, C);
 }
 
 __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
     const float *__restrict__ means, const float *__restrict__ L, int N, int H, int W, int tiles_x,
     int tiles_y, float center_bias, float *__restrict__ xys, float *__restrict__ depths,
     int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count, int row0, int row1)
+    int *tile_count, int *seg, int C, int row0, int row1, const DevStatus *status,
+    volatile long long *h_status, long long generation)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
     if (g >= N) return;
     float l11 = L[3 * g], l21 = L[3 * g + 1], l22 = L[3 * g + 2];
     float sxx = l11 * l11;
     float sxy = l11 * l21;
     float syy = l21 * l21 + l22 * l22;
     project_tail(g, means[2 * g], means[2 * g + 1], sxx, sxy, syy, H, W, tiles_x, tiles_y,
-                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count, row0, row1);
+                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count, seg, C, row0,
+                 row1);
 }
 
 __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
@@ -155,9 +210,11 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     const float *__restrict__ rot, int N, int H, int W, int tiles_x, int tiles_y,
     float center_bias, float *__restrict__ xys, float *__restrict__ depths,
     int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count, int row0, int row1)
+    int *tile_count, int *seg, int C, int row0, int row1, const DevStatus *status,
+    volatile long long *h_status, long long generation)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
     if (g >= N) return;
     float s, c;
     sincosf(rot[g], &s, &c);
@@ -167,7 +224,33 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     float sxy = c * s * (q1 - q2);
     float syy = s * s * q1 + c * c * q2;
     project_tail(g, means[2 * g], means[2 * g + 1], sxx, sxy, syy, H, W, tiles_x, tiles_y,
-                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count, row0, row1);
+                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count, seg, C, row0,
+                 row1);
+}
+
+// Binning from caller-made xys / radii (no projection in front of it).
+__global__ __launch_bounds__(256) void bin_tiles_kernel(const float *__restrict__ xys,
+                                                         const int *__restrict__ radii, int N,
+                                                         int tiles_x, int tiles_y, int row0,
+                                                         int row1, int *tile_count, int *seg, int C,
+                                                         const DevStatus *status,
+                                                         volatile long long *h_status,
+                                                         long long generation)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) publish_status(status, h_status, generation);
+    if (g >= N) return;
+    const int r = radii[g];
+    const float cx = xys[2 * g], cy = xys[2 * g + 1];
+    if (r <= 0) return;
+    TileBox box = tile_box(cx, cy, (float)r, tiles_x, tiles_y);
+    emit_tiles(g, box, row0, row1, tiles_x, tile_count, seg, C);
+}
+
+__global__ __launch_bounds__(256) void zero_ints_kernel(int *p, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
 }
 
 // dL/dSigma from dL/dconic: with C = Sigma^-1 and V = [[va, vb/2],[vb/2, vc]], G = -C V C;
@@ -250,151 +333,8 @@ __global__ __launch_bounds__(256) void project_rs_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// tile binning: count -> scan -> fill -> per-tile sort
+// per-tile sorting
 // ------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(256) void zero_ints_kernel(int *p, int n)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0;
-}
-
-__global__ __launch_bounds__(256) void count_tiles_kernel(const float *__restrict__ xys,
-                                                           const int *__restrict__ radii, int N,
-                                                           int tiles_x, int tiles_y, int row0,
-                                                           int row1, int *tile_count)
-{
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    int r = radii[g];
-    if (r <= 0) return;
-    TileBox box = tile_box(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y);
-    const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = box.x0; tx < box.x1; ++tx)
-            atomicAdd(&tile_count[((ty - row0) * tiles_x + tx) * CNT_STRIDE], 1);
-}
-
-// One workgroup: exclusive scan of the per-tile counts into tile_offsets[T+1]; leaves the
-// counters at zero so that the fill kernel can use them as per-tile cursors.
-__global__ __launch_bounds__(1024) void scan_tiles_kernel(int *tile_count, int *tile_offsets, int T,
-                                                           long long ids_cap, DevStatus *status,
-                                                           long long generation)
-{
-    __shared__ long long wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (T + 1023) / 1024;
-    const int b = min(T, tid * chunk), e = min(T, b + chunk);
-    // up to SCAN_REG counters per lane stay in registers: one round trip to memory, not two
-    constexpr int SCAN_REG = 8;
-    int c[SCAN_REG];
-    long long s = 0;
-    if (chunk <= SCAN_REG) {
-#pragma unroll
-        for (int u = 0; u < SCAN_REG; ++u)
-            c[u] = (b + u < e) ? tile_count[(size_t)(b + u) * CNT_STRIDE] : 0;
-#pragma unroll
-        for (int u = 0; u < SCAN_REG; ++u) s += c[u];
-    } else {
-        for (int i = b; i < e; ++i) s += tile_count[(size_t)i * CNT_STRIDE];
-    }
-    long long inc = s;
-    for (int d = 1; d < 64; d <<= 1) {
-        long long o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    long long wbase = 0, total = 0;
-    for (int w = 0; w < 16; ++w) {
-        long long v = wave_tot[w];
-        if (w < wave) wbase += v;
-        total += v;
-    }
-    const bool over = total > ids_cap || total >= (long long)INT_MAX;
-    long long run = wbase + inc - s;
-    if (chunk <= SCAN_REG) {
-#pragma unroll
-        for (int u = 0; u < SCAN_REG; ++u)
-            if (b + u < e) {
-                tile_offsets[b + u] = (int)(run < (long long)INT_MAX ? run : (long long)INT_MAX);
-                run += c[u];
-                tile_count[(size_t)(b + u) * CNT_STRIDE] = 0;
-            }
-    } else {
-        for (int i = b; i < e; ++i) {
-            int ci = tile_count[(size_t)i * CNT_STRIDE];
-            tile_offsets[i] = (int)(run < (long long)INT_MAX ? run : (long long)INT_MAX);
-            run += ci;
-            tile_count[(size_t)i * CNT_STRIDE] = 0;
-        }
-    }
-    if (tid == 0) {
-        // tile_offsets[T] doubles as the overflow sentinel every later kernel reads together
-        // with its own list bounds: -1 = the lists do not fit, skip
-        tile_offsets[T] = over ? -1 : (int)total;
-        status->overflow = over ? 1 : 0;
-        status->total = total;
-        status->generation = generation;
-    }
-}
-
-__global__ __launch_bounds__(256) void fill_tiles_kernel(const float *__restrict__ xys,
-                                                          const int *__restrict__ radii, int N,
-                                                          int tiles_x, int tiles_y, int row0,
-                                                          int row1,
-                                                          const int *__restrict__ tile_offsets,
-                                                          int *tile_cursor, int *ids, int T,
-                                                          const DevStatus *status,
-                                                          volatile long long *h_status)
-{
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) {
-        // Host-visible copy of the count (pinned memory, read without synchronisation by the
-        // next calls).  Issued first so that the slow host write overlaps the rest of the kernel.
-        const long long total = status->total, gen = status->generation;
-        h_status[0] = total;
-        h_status[1] = gen;
-        if (status->overflow) h_status[2] = gen;
-    }
-    if (g >= N) return;
-    const int r = radii[g];
-    const float cx = xys[2 * g], cy = xys[2 * g + 1];
-    if (tile_offsets[T] < 0) return;  // overflow
-    if (r <= 0) return;
-    TileBox box = tile_box(cx, cy, (float)r, tiles_x, tiles_y);
-    const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
-    const int w = box.x1 - box.x0;
-    const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
-    // Four returning atomics are put in flight before the first dependent store: a lane's
-    // round trips overlap instead of adding up.
-    int tx = box.x0, ty = y0;
-    for (int k0 = 0; k0 < cnt; k0 += 4) {
-        int t[4], pos[4], off[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            t[u] = (k0 + u < cnt) ? (ty - row0) * tiles_x + tx : -1;
-            if (++tx >= box.x1) {
-                tx = box.x0;
-                ++ty;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            pos[u] = 0;
-            off[u] = 0;
-            if (t[u] >= 0) {
-                pos[u] = atomicAdd(&tile_cursor[(size_t)t[u] * CNT_STRIDE], 1);
-                off[u] = tile_offsets[t[u]];
-            }
-        }
-        // slot 0 is always live here; dead slots repeat its store so that the four stores
-        // issue back to back without control flow (and the waits it brings) between them
-        const int first = off[0] + pos[0];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ids[t[u] >= 0 ? off[u] + pos[u] : first] = g;
-    }
-}
 
 // ascending in-place bitonic network; elements past n are a virtual +infinity
 template <typename P>
@@ -433,8 +373,6 @@ __device__ __forceinline__ void bitonic_sort(P a, int n, int lane, int nthreads)
     }
 }
 
-#define SORT_LDS_MAX 4096
-
 // Rank sort of up to 64*R distinct ints held R per lane: every value is broadcast once with
 // v_readlane and each lane counts how many are smaller than its own.  No LDS, no barrier.
 template <int R>
@@ -461,35 +399,53 @@ __device__ __forceinline__ void rank_sort_regs(int *ids, int beg, int n, int lan
         if (r * WAVE + lane < n) ids[beg + rank[r]] = v[r];
 }
 
-// One wave per tile: puts the tile's Gaussian ids in ascending order (the fill order depends
-// on atomic arrival) and returns the tile's cursor to zero for the next binning.  The launch
-// lasts as long as its slowest tile, so lists up to 256 entries stay on the register path;
-// longer ones use a bitonic network in LDS, and beyond the LDS budget in place in memory.
-__global__ __launch_bounds__(WAVE) void sort_tiles_kernel(const int *__restrict__ tile_offsets,
-                                                          int *ids, int *tile_cursor, int T)
+
+#define SORT_LDS_MAX 4096
+
+// What a tile does once per binning, whoever gets there first (the standalone kernel below or
+// the first rasterisation): publish the list length, return the counter to zero for the next
+// frame, and note a nearly full or overflowed segment for the capacity policy.
+__device__ __forceinline__ void finalize_tile_words(int t, int n_raw, int C, int *tile_count,
+                                                    int *tile_len, DevStatus *status,
+                                                    long long generation)
+{
+    tile_len[t] = n_raw;
+    tile_count[(size_t)t * CNT_STRIDE] = 0;
+    if (2 * n_raw > C) atomicMax(&status->max_count, n_raw);  // rare by construction
+    if (n_raw > C) status->overflow_gen = generation;
+}
+
+// One wave per tile: puts the tile's ids in ascending order and finalises the tile.  The
+// launch lasts as long as its slowest tile, so lists up to 256 entries stay on the register
+// path; longer ones use a bitonic network in LDS, beyond the LDS budget in place in memory.
+// Used when nothing rasterises right after a binning (backward first, list read-back, the
+// synchronous capacity check); otherwise the forward rasteriser does this work itself.
+__global__ __launch_bounds__(WAVE) void finalize_tiles_kernel(int *tile_count, int *tile_len,
+                                                              int *seg, int C, DevStatus *status,
+                                                              long long generation)
 {
     __shared__ int s_ids[SORT_LDS_MAX];
     const int t = blockIdx.x, lane = threadIdx.x;
-    // the three list words are independent loads: one round trip
-    const int beg = tile_offsets[t], fin = tile_offsets[t + 1], sentinel = tile_offsets[T];
-    const int n = sentinel < 0 ? 0 : fin - beg;
+    const int n_raw = tile_count[(size_t)t * CNT_STRIDE];
+    const int n = min(n_raw, C);
+    int *ids = seg + (size_t)t * C;
     if (n > 1) {
         if (n <= WAVE) {
-            rank_sort_regs<1>(ids, beg, n, lane);
+            rank_sort_regs<1>(ids, 0, n, lane);
         } else if (n <= 2 * WAVE) {
-            rank_sort_regs<2>(ids, beg, n, lane);
+            rank_sort_regs<2>(ids, 0, n, lane);
         } else if (n <= 4 * WAVE) {
-            rank_sort_regs<4>(ids, beg, n, lane);
+            rank_sort_regs<4>(ids, 0, n, lane);
         } else if (n <= SORT_LDS_MAX) {
-            for (int i = lane; i < n; i += WAVE) s_ids[i] = ids[beg + i];
+            for (int i = lane; i < n; i += WAVE) s_ids[i] = ids[i];
             __syncthreads();
             bitonic_sort(s_ids, n, lane, WAVE);
-            for (int i = lane; i < n; i += WAVE) ids[beg + i] = s_ids[i];
+            for (int i = lane; i < n; i += WAVE) ids[i] = s_ids[i];
         } else {
-            bitonic_sort(ids + beg, n, lane, WAVE);
+            bitonic_sort(ids, n, lane, WAVE);
         }
     }
-    if (lane == 0) tile_cursor[(size_t)t * CNT_STRIDE] = 0;
+    if (lane == 0) finalize_tile_words(t, n_raw, C, tile_count, tile_len, status, generation);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,21 +503,29 @@ __device__ __forceinline__ int xcd_tile(int bid, int T)
 // each entry's support rectangle yields a 4-bit quadrant mask, a ballot turns the masks of 64
 // entries into one 64-bit scalar per wave, and the wave walks only the set bits (scalar bit
 // scan), reading each surviving entry's record from LDS as a broadcast.
+//
+// FINALIZE = true (first pass after a binning): the workgroup first puts its segment in
+// ascending id order -- for a list of up to 256 ids that is a rank computed from LDS broadcasts
+// while the records are staged, so it costs no extra round trip to memory -- writes the sorted
+// ids back for the later passes and the backward, and finalises the tile's words.
 // ------------------------------------------------------------------------------------------
 
-#define LOG2E 1.4426950408889634f
+#define FWD_LDS_INTS 2816  // 11 KB of LDS: the staging records, or the sort buffer of a long list
 
+template <bool FINALIZE>
 __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
-    const int *__restrict__ tile_offsets, const int *__restrict__ ids,
-    const float *__restrict__ xys, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacity, float bg0, float bg1,
-    float bg2, int H, int W, int tiles_x, int row0, int T, gi2d_conv cv, int cull,
+    int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, float bg0, float bg1, float bg2, int H, int W, int tiles_x,
+    int row0, int T, gi2d_conv cv, int cull, DevStatus *status, long long generation,
     float *__restrict__ out)
 {
-    __shared__ float4 s_a[256];  // gx, gy, -0.5*a*log2e, -b*log2e
-    __shared__ float4 s_b[256];  // -0.5*c*log2e, opacity, colour r, colour g
-    __shared__ float s_c[256];   // colour b
-    __shared__ int s_m[256];     // quadrant mask of the entry (bit = 2*qy + qx)
+    __shared__ __attribute__((aligned(16))) int smem[FWD_LDS_INTS];
+    float4 *s_a = reinterpret_cast<float4 *>(smem);         // gx, gy, -0.5*a*log2e, -b*log2e
+    float4 *s_b = reinterpret_cast<float4 *>(smem + 1024);  // -0.5*c*log2e, opacity, r, g
+    float *s_c = reinterpret_cast<float *>(smem + 2048);    // b
+    int *s_m = smem + 2304;                                 // quadrant mask (bit = 2*qy + qx)
+    int *s_id = smem + 2560;                                // ids of the batch (rank sort)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_tile(blockIdx.x, T);
     const int tx = t % tiles_x, ty = row0 + t / tiles_x;
@@ -569,64 +533,97 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     const int j = tx * GI2D_BLOCK + lx, i = ty * GI2D_BLOCK + ly;
     const bool inside = (i < H) && (j < W);
     const float px = (float)j + cv.pixel_offset, py = (float)i + cv.pixel_offset;
+    int *lst = seg + (size_t)t * C;
+    // the first batch's id is loaded before the list length is known (a segment always has C
+    // words): one round trip to memory instead of two
+    int gid_first = tid < C ? lst[tid] : 0;
+    const int n_raw = FINALIZE ? tile_count[(size_t)t * CNT_STRIDE] : tile_len[t];
+    const int n_all = min(n_raw, C);
     float r = 0.f, g = 0.f, b = 0.f;
-    // list bounds and the overflow sentinel: three independent loads, one round trip
-    const int beg = tile_offsets[t], end = tile_offsets[t + 1], sentinel = tile_offsets[T];
-    if (sentinel < 0) {
-        r = g = b = __builtin_nanf("");  // the lists did not fit: never a silently wrong image
-    } else {
-        const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
-        const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
-        const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
-        const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
-        for (int base = beg; base < end; base += 256) {
-            const int n = min(256, end - base);
-            __syncthreads();
-            int mask = 0;
-            if (tid < n) {
-                const int gid = ids[base + tid];
-                const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
-                const float ca = conics[3 * gid], cb = conics[3 * gid + 1], cc = conics[3 * gid + 2];
-                const float op = opacity[gid];
-                s_a[tid] = make_float4(gx, gy, (-0.5f * LOG2E) * ca, (-LOG2E) * cb);
-                s_b[tid] = make_float4((-0.5f * LOG2E) * cc, op, colors[3 * gid],
-                                       colors[3 * gid + 1]);
-                s_c[tid] = colors[3 * gid + 2];
-                int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
-                if (cull) support_rect(gx, gy, ca, cb, cc, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
-                if (x0 <= x1 && y0 <= y1) {
-                    const int mx = (x0 < 8 ? 1 : 0) | (x1 >= 8 ? 2 : 0);
-                    const int my = (y0 < 8 ? 1 : 0) | (y1 >= 8 ? 2 : 0);
-                    mask = ((my & 1) ? mx : 0) | ((my & 2) ? (mx << 2) : 0);
-                }
+    if (FINALIZE) {
+        __syncthreads();  // every wave has read the counter before lane 0 returns it to zero
+        if (n_all > 256) {  // long list: sort it where it lies before the batches are read
+            if (n_all <= FWD_LDS_INTS) {
+                for (int k = tid; k < n_all; k += 256) smem[k] = lst[k];
+                __syncthreads();
+                bitonic_sort(smem, n_all, tid, 256);
+                for (int k = tid; k < n_all; k += 256) lst[k] = smem[k];
+            } else {
+                bitonic_sort(lst, n_all, tid, 256);
             }
-            s_m[tid] = mask;
             __syncthreads();
-            for (int c0 = 0; c0 < n; c0 += 64) {
-                unsigned long long bits = __ballot((s_m[c0 + lane] >> wave) & 1);
-                while (bits) {
-                    const int k = c0 + (int)__builtin_ctzll(bits);
-                    bits &= bits - 1;
-                    const float4 A = s_a[k];
-                    const float4 B = s_b[k];
-                    const float cb = s_c[k];
-                    const float dx = A.x - px, dy = A.y - py;
-                    // p = -sigma*log2(e) = (A'dx + B'dy)dx + C'dy*dy
-                    const float q = __builtin_fmaf(A.w, dy, A.z * dx);
-                    const float p = __builtin_fmaf(B.x * dy, dy, q * dx);
-                    const float e = __builtin_amdgcn_exp2f(p);
-                    const float alpha = fminf(cv.alpha_cap, B.y * e);
-                    const float w = (p > 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
-                    r = __builtin_fmaf(B.z, w, r);
-                    g = __builtin_fmaf(B.w, w, g);
-                    b = __builtin_fmaf(cb, w, b);
-                }
+        }
+        if (tid == 0) finalize_tile_words(t, n_raw, C, tile_count, tile_len, status, generation);
+    }
+    const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
+    const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
+    const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
+    const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
+    for (int base = 0; base < n_all; base += 256) {
+        const int n = min(256, n_all - base);
+        __syncthreads();
+        // (a long list was just re-sorted in place: the early copy of its first ids is stale)
+        const bool early = base == 0 && !(FINALIZE && n_all > 256);
+        const int gid = tid < n ? (early ? gid_first : lst[base + tid]) : INT_MAX;
+        int slot = tid;
+        if (FINALIZE && n_all <= 256) {
+            // rank of my id among the batch = its place in ascending order (ids are distinct)
+            s_id[tid] = gid;
+            __syncthreads();
+            int rank = 0;
+            for (int k = 0; k < n; k += 4) {
+                const int4 q = *reinterpret_cast<const int4 *>(s_id + k);
+                rank += (q.x < gid ? 1 : 0) + (q.y < gid ? 1 : 0) + (q.z < gid ? 1 : 0) +
+                        (q.w < gid ? 1 : 0);
+            }
+            if (tid < n) {
+                lst[rank] = gid;
+                slot = rank;
             }
         }
-        r = r + cv.bg_weight * bg0;
-        g = g + cv.bg_weight * bg1;
-        b = b + cv.bg_weight * bg2;
+        int mask = 0;
+        if (tid < n) {
+            const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
+            const float ca = conics[3 * gid], cb = conics[3 * gid + 1], cc = conics[3 * gid + 2];
+            const float op = opacity[gid];
+            s_a[slot] = make_float4(gx, gy, (-0.5f * LOG2E) * ca, (-LOG2E) * cb);
+            s_b[slot] = make_float4((-0.5f * LOG2E) * cc, op, colors[3 * gid], colors[3 * gid + 1]);
+            s_c[slot] = colors[3 * gid + 2];
+            int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
+            if (cull) support_rect(gx, gy, ca, cb, cc, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
+            if (x0 <= x1 && y0 <= y1) {
+                const int mx = (x0 < 8 ? 1 : 0) | (x1 >= 8 ? 2 : 0);
+                const int my = (y0 < 8 ? 1 : 0) | (y1 >= 8 ? 2 : 0);
+                mask = ((my & 1) ? mx : 0) | ((my & 2) ? (mx << 2) : 0);
+            }
+        }
+        s_m[slot] = mask;  // lanes past the batch keep slot = tid >= n and store 0
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            unsigned long long bits = __ballot((s_m[c0 + lane] >> wave) & 1);
+            while (bits) {
+                const int k = c0 + (int)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                const float4 A = s_a[k];
+                const float4 B = s_b[k];
+                const float cb = s_c[k];
+                const float dx = A.x - px, dy = A.y - py;
+                // p = -sigma*log2(e) = (A'dx + B'dy)dx + C'dy*dy
+                const float q = __builtin_fmaf(A.w, dy, A.z * dx);
+                const float p = __builtin_fmaf(B.x * dy, dy, q * dx);
+                const float e = __builtin_amdgcn_exp2f(p);
+                const float alpha = fminf(cv.alpha_cap, B.y * e);
+                const float w = (p > 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
+                r = __builtin_fmaf(B.z, w, r);
+                g = __builtin_fmaf(B.w, w, g);
+                b = __builtin_fmaf(cb, w, b);
+            }
+        }
     }
+    r = r + cv.bg_weight * bg0;
+    g = g + cv.bg_weight * bg1;
+    b = b + cv.bg_weight * bg2;
+    if (n_raw > C) r = g = b = __builtin_nanf("");  // overflowed segment: never silently wrong
     if (inside) {
         float *o = out + 3 * ((size_t)(i - row0 * GI2D_BLOCK) * W + j);
         o[0] = r;
@@ -638,20 +635,17 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
 // ------------------------------------------------------------------------------------------
 // rasterize_sum backward.
 //
-// Pass 1 (one workgroup per tile): lane = (list entry, 4-row strip of the tile).  Each lane
-// walks only the pixels of its strip that lie inside the entry's support rectangle (the
-// bounding box of the ellipse alpha >= alpha_min), keeps the entry's nine partial sums in
-// registers, the four strips are added with two DPP steps, and the tile's sums are written to
-// the entry's own slot of a [slots][9] slab -- no cross-lane tree, no atomics.
-// Pass 2 (one lane per Gaussian): adds the Gaussian's slots in tile order; a slot is found by
-// binary search because tile lists are ascending in Gaussian id.
+// Pass 1 (one workgroup per tile): a quad of lanes per list entry.  The quad walks only the
+// pixels of the entry's support rectangle (bounding box of the ellipse alpha >= alpha_min),
+// round-robin over its four lanes, keeps the entry's nine partial sums in registers, adds the
+// four lanes with two DPP steps and writes the sums to the entry's own slot of a [slots][9]
+// slab -- no cross-lane tree, no atomics -- and notes the slot in a small per-Gaussian table.
+// Pass 2 (one lane per Gaussian): adds the Gaussian's slots in tile order; slots of the first
+// SLOT_TAB tiles come from the table, the rest by binary search (lists ascend in Gaussian id).
 // ------------------------------------------------------------------------------------------
 
-#define PART_STRIDE 9
-#define SLOT_TAB 4  // slots per Gaussian remembered by pass 1 (tile boxes are mostly <= 2x2)
-
 __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
-    const int *__restrict__ tile_offsets, const int *__restrict__ ids,
+    const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
     const float *__restrict__ xys, const int *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
@@ -661,8 +655,10 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     __shared__ float4 s_v[256];
     const int tid = threadIdx.x;
     const int t = xcd_tile(blockIdx.x, T);
-    const int beg = tile_offsets[t], end = tile_offsets[t + 1], sentinel = tile_offsets[T];
-    if (sentinel < 0 || beg == end) return;
+    const int n_raw = tile_len[t];
+    if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
+    const int *lst = seg + (size_t)t * C;
+    const size_t slot0 = (size_t)t * C;
     const int tx = t % tiles_x, ty = row0 + t / tiles_x;
     {
         const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
@@ -681,15 +677,15 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
     const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
     const int q = tid & 3;
-    for (int base = beg; base < end; base += 64) {
+    for (int base = 0; base < n_raw; base += 64) {
         const int e = base + (tid >> 2);
         float acc[PART_STRIDE];
 #pragma unroll
         for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
         int gid = 0, rad = 0;
         float gx = 0.f, gy = 0.f;
-        if (e < end) {
-            gid = ids[e];
+        if (e < n_raw) {
+            gid = lst[e];
             gx = xys[2 * gid];
             gy = xys[2 * gid + 1];
             rad = radii[gid];
@@ -741,12 +737,12 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
         }
 #pragma unroll
         for (int k = 0; k < PART_STRIDE; ++k) acc[k] = quad_sum(acc[k]);
-        if (e < end && q == 0) {
-            float *dst = partials + (size_t)e * PART_STRIDE;
+        if (e < n_raw && q == 0) {
+            float *dst = partials + (slot0 + e) * PART_STRIDE;
 #pragma unroll
             for (int k = 0; k < PART_STRIDE; ++k) dst[k] = acc[k];
-            // where the second pass finds this slot without searching: index of this tile in
-            // the Gaussian's own (band-clipped) tile box, first SLOT_TAB tiles only
+            // where pass 2 finds this slot without searching: index of this tile in the
+            // Gaussian's own (band-clipped) tile box, first SLOT_TAB tiles only
             if (rad > 0) {
                 TileBox box = tile_box(gx, gy, (float)rad, tiles_x, tiles_y);
                 const int by0 = max(box.y0, row0);
@@ -759,7 +755,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
 
 __global__ __launch_bounds__(256) void gather_grads_kernel(
     const float *__restrict__ xys, const int *__restrict__ radii, int N, int tiles_x, int tiles_y,
-    int row0, int row1, int T, const int *__restrict__ tile_offsets, const int *__restrict__ ids,
+    int row0, int row1, const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
     const float *__restrict__ partials, const int *__restrict__ slot_tab,
     float *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_colors,
     float *__restrict__ v_opacity)
@@ -772,42 +768,51 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(
     const int r = radii[g];
     const float cx = xys[2 * g], cy = xys[2 * g + 1];
     const int4 tab = *reinterpret_cast<const int4 *>(slot_tab + (size_t)g * SLOT_TAB);
-    const int sentinel = tile_offsets[T];
-    if (r > 0 && sentinel >= 0) {
+    if (r > 0) {
         TileBox box = tile_box(cx, cy, (float)r, tiles_x, tiles_y);
         const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
         const int w = box.x1 - box.x0;
         const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
-        // the first SLOT_TAB tiles: slots remembered by pass 1, loads independent of each other
-        {
-            const int slots[SLOT_TAB] = {tab.x, tab.y, tab.z, tab.w};
-            float part[SLOT_TAB][PART_STRIDE];
+        // Tiles of the box in row-major order.  The first SLOT_TAB: list position remembered by
+        // pass 1; the loads of the four slots are independent of each other.
+        int tl[SLOT_TAB], ln[SLOT_TAB];
+        const int pos[SLOT_TAB] = {tab.x, tab.y, tab.z, tab.w};
 #pragma unroll
-            for (int k = 0; k < SLOT_TAB; ++k) {
-                const float *src = partials + (size_t)(k < cnt ? slots[k] : 0) * PART_STRIDE;
-#pragma unroll
-                for (int u = 0; u < PART_STRIDE; ++u) part[k][u] = (k < cnt) ? src[u] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < SLOT_TAB; ++k)
-#pragma unroll
-                for (int u = 0; u < PART_STRIDE; ++u) acc[u] += part[k][u];
+        for (int k = 0; k < SLOT_TAB; ++k) {
+            const int ty = w > 0 ? y0 + k / w : 0, tx = w > 0 ? box.x0 + k % w : 0;
+            tl[k] = k < cnt ? (ty - row0) * tiles_x + tx : 0;
+            ln[k] = k < cnt ? tile_len[tl[k]] : 0;
         }
-        // larger boxes: the rest by binary search (tile lists ascend in Gaussian id)
+        float part[SLOT_TAB][PART_STRIDE];
+#pragma unroll
+        for (int k = 0; k < SLOT_TAB; ++k) {
+            // an overflowed tile (ln > C) wrote no partial sums
+            const bool live = k < cnt && ln[k] <= C && pos[k] >= 0 && pos[k] < ln[k];
+            const float *src = partials + ((size_t)tl[k] * C + (live ? pos[k] : 0)) * PART_STRIDE;
+#pragma unroll
+            for (int u = 0; u < PART_STRIDE; ++u) part[k][u] = live ? src[u] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < SLOT_TAB; ++k)
+#pragma unroll
+            for (int u = 0; u < PART_STRIDE; ++u) acc[u] += part[k][u];
+        // larger boxes: the rest by binary search
         for (int k = SLOT_TAB; k < cnt; ++k) {
             const int ty = y0 + k / w, tx = box.x0 + k % w;
             const int t = (ty - row0) * tiles_x + tx;
-            int lo = tile_offsets[t], hi = tile_offsets[t + 1];
-            const int fin = hi;
-            while (lo < hi) {  // first slot with id >= g
+            const int n = tile_len[t];
+            if (n > C) continue;
+            const int *lst = seg + (size_t)t * C;
+            int lo = 0, hi = n;
+            while (lo < hi) {  // first position with id >= g
                 int mid = (lo + hi) >> 1;
-                if (ids[mid] < g)
+                if (lst[mid] < g)
                     lo = mid + 1;
                 else
                     hi = mid;
             }
-            if (lo < fin && ids[lo] == g) {
-                const float *src = partials + (size_t)lo * PART_STRIDE;
+            if (lo < n && lst[lo] == g) {
+                const float *src = partials + ((size_t)t * C + lo) * PART_STRIDE;
 #pragma unroll
                 for (int u = 0; u < PART_STRIDE; ++u) acc[u] += src[u];
             }
@@ -893,27 +898,29 @@ __global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScala
 
 struct gi2d_workspace {
     int device = 0;
-    int tiles_cap = 0;
-    int *d_count = nullptr;     // [tiles_cap] per-tile counters / cursors, zero between calls
-    int *d_offsets = nullptr;   // [tiles_cap + 1]
-    int64_t ids_cap = 0;
-    int *d_ids = nullptr;
-    int64_t part_cap = 0;
-    float *d_partials = nullptr;
+    int tiles_cap = 0;          // tiles the per-tile arrays are allocated for
+    int seg_cap = 0;            // C: ids per tile segment
+    int *d_count = nullptr;     // [tiles_cap][CNT_STRIDE] per-tile counters, zero between frames
+    int *d_len = nullptr;       // [tiles_cap] list length of the finalised lists
+    int *d_seg = nullptr;       // [tiles_cap][seg_cap] Gaussian ids per tile
+    int64_t part_slots = 0;
+    float *d_partials = nullptr;  // [tiles][seg_cap][9] backward partial sums
     int64_t slot_cap = 0;
-    int *d_slot_tab = nullptr;  // [n][SLOT_TAB] slot of a Gaussian in its first tiles (backward)
+    int *d_slot_tab = nullptr;  // [n][SLOT_TAB] list position of a Gaussian in its first tiles
     DevStatus *d_status = nullptr;
-    long long *h_status = nullptr;   // pinned: [0] total, [1] generation, [2] overflow generation
+    long long *h_status = nullptr;  // pinned: [0] max count, [1] generation, [2] overflow gen.
     long long *h_status_dev = nullptr;
     int64_t generation = 0;
     int64_t overflow_ack = 0;
     int tiles_x = 0, tiles_y = 0, n_binned = 0;
-    int row0 = 0, row1 = INT_MAX;          // tile rows requested by the caller (a band)
-    int bin_row0 = 0, bin_row1 = 0;        // tile rows of the current lists
-    bool counters_dirty = false;  // counters may be non-zero (a binning was cut short)
-    bool counted = false;         // project_*_fwd accumulated counts for (n, tiles) below
-    int counted_n = 0, counted_tx = 0, counted_ty = 0, counted_r0 = 0, counted_r1 = 0;
+    int row0 = 0, row1 = INT_MAX;    // tile rows requested by the caller (a band)
+    int bin_row0 = 0, bin_row1 = 0;  // tile rows of the current lists
+    bool counters_dirty = false;     // counters may be non-zero
+    bool lists_raw = false;          // lists filled but not yet sorted / finalised
+    bool prefilled = false;          // project_*_fwd filled the lists for the shape below
+    int pre_n = 0, pre_tx = 0, pre_ty = 0, pre_r0 = 0, pre_r1 = 0;
     int cull = 1;
+    int min_seg_cap = 64;
 };
 
 #define HIP_TRY(expr)                                \
@@ -929,6 +936,7 @@ static inline int launch_status()
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 
 namespace {
 struct DeviceGuard {
@@ -947,6 +955,70 @@ struct DeviceGuard {
 };
 }  // namespace
 
+// (Re)allocates the per-tile arrays for T tiles of C ids each; the device is current.
+// Contents are lost: callers re-bin afterwards.
+static int ensure_lists(gi2d_workspace *ws, int T, int C)
+{
+    if (T <= ws->tiles_cap && C <= ws->seg_cap) return GI2D_OK;
+    T = T > ws->tiles_cap ? T : ws->tiles_cap;
+    C = C > ws->seg_cap ? C : ws->seg_cap;
+    if ((int64_t)T * C >= (int64_t)INT_MAX) return GI2D_E_CAPACITY;
+    HIP_TRY(hipDeviceSynchronize());
+    if (ws->d_count) (void)hipFree(ws->d_count);
+    if (ws->d_len) (void)hipFree(ws->d_len);
+    if (ws->d_seg) (void)hipFree(ws->d_seg);
+    if (ws->d_partials) (void)hipFree(ws->d_partials);
+    ws->d_count = ws->d_len = ws->d_seg = nullptr;
+    ws->d_partials = nullptr;
+    ws->part_slots = 0;
+    ws->tiles_cap = ws->seg_cap = 0;
+    HIP_TRY(hipMalloc(&ws->d_count, sizeof(int) * CNT_STRIDE * (size_t)T));
+    HIP_TRY(hipMalloc(&ws->d_len, sizeof(int) * (size_t)T));
+    HIP_TRY(hipMalloc(&ws->d_seg, sizeof(int) * (size_t)T * C));
+    HIP_TRY(hipMemset(ws->d_count, 0, sizeof(int) * CNT_STRIDE * (size_t)T));
+    HIP_TRY(hipMemset(ws->d_len, 0, sizeof(int) * (size_t)T));
+    ws->tiles_cap = T;
+    ws->seg_cap = C;
+    ws->counters_dirty = false;
+    ws->lists_raw = false;
+    ws->prefilled = false;
+    ws->tiles_x = ws->tiles_y = 0;  // no valid lists
+    return GI2D_OK;
+}
+
+// Segment capacity wanted for a largest per-tile count `seen`: twice it, in whole waves.
+static inline int wanted_cap(const gi2d_workspace *ws, long long seen)
+{
+    long long c = 2 * seen;
+    if (c < ws->min_seg_cap) c = ws->min_seg_cap;
+    if (c > (long long)INT_MAX / 4) c = INT_MAX / 4;
+    return round_up((int)c, WAVE);
+}
+
+static int zero_counters(gi2d_workspace *ws, hipStream_t st)
+{
+    const int n = ws->tiles_cap * CNT_STRIDE;
+    if (n == 0) return GI2D_OK;
+    zero_ints_kernel<<<cdiv(n, 256), 256, 0, st>>>(ws->d_count, n);
+    return launch_status();
+}
+
+// Sorts and finalises raw lists (when no forward rasterisation does it).
+static int finalize_lists(gi2d_workspace *ws, hipStream_t st)
+{
+    if (!ws->lists_raw) return GI2D_OK;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (T > 0) {
+        finalize_tiles_kernel<<<T, WAVE, 0, st>>>(ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap,
+                                                  ws->d_status, ws->generation);
+        int rc = launch_status();
+        if (rc != GI2D_OK) return rc;
+    }
+    ws->lists_raw = false;
+    ws->counters_dirty = false;
+    return GI2D_OK;
+}
+
 extern "C" {
 
 int gi2d_version(void) { return GI2D_VERSION; }
@@ -959,8 +1031,8 @@ const char *gi2d_error_string(int status)
         case GI2D_E_STATE: return "workspace holds no tile lists for this call";
         case GI2D_E_CAPACITY: return "tile-list capacity exceeded";
         case GI2D_E_PREV_OVERFLOW:
-            return "an earlier asynchronous frame overflowed the tile lists (its image is NaN); "
-                   "the workspace was grown, call again";
+            return "an earlier asynchronous frame overflowed a tile list (those tiles of its "
+                   "image are NaN); the workspace was grown, call again";
         default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown error";
     }
 }
@@ -1005,8 +1077,8 @@ int gi2d_workspace_destroy(gi2d_workspace *ws)
     DeviceGuard guard(ws->device);
     (void)hipDeviceSynchronize();
     if (ws->d_count) (void)hipFree(ws->d_count);
-    if (ws->d_offsets) (void)hipFree(ws->d_offsets);
-    if (ws->d_ids) (void)hipFree(ws->d_ids);
+    if (ws->d_len) (void)hipFree(ws->d_len);
+    if (ws->d_seg) (void)hipFree(ws->d_seg);
     if (ws->d_partials) (void)hipFree(ws->d_partials);
     if (ws->d_slot_tab) (void)hipFree(ws->d_slot_tab);
     if (ws->d_status) (void)hipFree(ws->d_status);
@@ -1015,47 +1087,14 @@ int gi2d_workspace_destroy(gi2d_workspace *ws)
     return GI2D_OK;
 }
 
-// (Re)allocates the per-tile arrays; callers have made the device current.
-static int ensure_tiles(gi2d_workspace *ws, int T)
+int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int max_tiles)
 {
-    if (T <= ws->tiles_cap) return GI2D_OK;
-    HIP_TRY(hipDeviceSynchronize());
-    if (ws->d_count) (void)hipFree(ws->d_count);
-    if (ws->d_offsets) (void)hipFree(ws->d_offsets);
-    ws->d_count = ws->d_offsets = nullptr;
-    ws->tiles_cap = 0;
-    HIP_TRY(hipMalloc(&ws->d_count, sizeof(int) * CNT_STRIDE * (size_t)T));
-    HIP_TRY(hipMalloc(&ws->d_offsets, sizeof(int) * ((size_t)T + 1)));
-    HIP_TRY(hipMemset(ws->d_count, 0, sizeof(int) * CNT_STRIDE * (size_t)T));
-    HIP_TRY(hipMemset(ws->d_offsets, 0, sizeof(int) * ((size_t)T + 1)));
-    ws->tiles_cap = T;
-    ws->counters_dirty = false;
-    ws->counted = false;
-    ws->tiles_x = ws->tiles_y = 0;
-    return GI2D_OK;
-}
-
-static int ensure_ids(gi2d_workspace *ws, int64_t need)
-{
-    if (need <= ws->ids_cap) return GI2D_OK;
-    if (need >= (int64_t)INT_MAX) return GI2D_E_CAPACITY;
-    HIP_TRY(hipDeviceSynchronize());
-    if (ws->d_ids) (void)hipFree(ws->d_ids);
-    ws->d_ids = nullptr;
-    ws->ids_cap = 0;
-    HIP_TRY(hipMalloc(&ws->d_ids, sizeof(int) * (size_t)need));
-    ws->ids_cap = need;
-    return GI2D_OK;
-}
-
-int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t max_intersections, int max_tiles)
-{
-    if (!ws || max_intersections < 0 || max_tiles < 0) return GI2D_E_INVALID;
+    if (!ws || per_tile_capacity < 0 || max_tiles < 0) return GI2D_E_INVALID;
+    if (per_tile_capacity > INT_MAX / 4) return GI2D_E_CAPACITY;
     DeviceGuard guard(ws->device);
     if (!guard.ok) return GI2D_E_INVALID;
-    int rc = ensure_tiles(ws, max_tiles);
-    if (rc != GI2D_OK) return rc;
-    return ensure_ids(ws, max_intersections);
+    const int C = round_up(per_tile_capacity > 1 ? (int)per_tile_capacity : 1, WAVE);
+    return ensure_lists(ws, max_tiles > 1 ? max_tiles : 1, C);
 }
 
 int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
@@ -1078,8 +1117,8 @@ int gi2d_workspace_set_rows(gi2d_workspace *ws, int row_begin, int row_end)
 int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[8])
 {
     if (!ws || !info) return GI2D_E_INVALID;
-    info[0] = ws->ids_cap;
-    info[1] = ws->h_status[1] == ws->generation ? ws->h_status[0] : -1;
+    info[0] = ws->seg_cap;
+    info[1] = ws->h_status[0];
     info[2] = ws->generation;
     info[3] = ws->tiles_x;
     info[4] = ws->tiles_y;
@@ -1099,25 +1138,37 @@ static int check_proj_args(const void *a, const void *b, int N, int H, int W, in
     return GI2D_OK;
 }
 
-// Prepares ws for a projection that also counts tiles.
-static int begin_fused_count(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream_t st)
+// True when the next binning of this shape must learn its list lengths synchronously.
+static bool shape_is_new(const gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int r0, int r1)
+{
+    return ws->seg_cap == 0 || ws->generation == 0 || N != ws->n_binned ||
+           tiles_x != ws->tiles_x || tiles_y != ws->tiles_y || r0 != ws->bin_row0 ||
+           r1 != ws->bin_row1;
+}
+
+// Prepares ws for a projection that also fills the tile lists.  Leaves ws->prefilled false when
+// the shape is new (the lists' capacity is unknown): gi2d_bin_tiles then bins synchronously.
+static int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream_t st)
 {
     const int r0 = min(ws->row0, tiles_y), r1 = min(ws->row1, tiles_y);
-    int rc = ensure_tiles(ws, max(1, (r1 - r0) * tiles_x));
+    const int T = (r1 - r0) * tiles_x;
+    ws->prefilled = false;
+    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1)) return GI2D_OK;
+    int rc = ensure_lists(ws, max(1, T), wanted_cap(ws, ws->h_status[0]));
     if (rc != GI2D_OK) return rc;
-    if (ws->counters_dirty || ws->counted) {
-        int T = ws->tiles_cap * CNT_STRIDE;
-        zero_ints_kernel<<<cdiv(T, 256), 256, 0, st>>>(ws->d_count, T);
-        rc = launch_status();
+    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1)) return GI2D_OK;  // reallocated
+    if (ws->counters_dirty) {
+        rc = zero_counters(ws, st);
         if (rc != GI2D_OK) return rc;
     }
     ws->counters_dirty = true;
-    ws->counted = true;
-    ws->counted_n = N;
-    ws->counted_tx = tiles_x;
-    ws->counted_ty = tiles_y;
-    ws->counted_r0 = r0;
-    ws->counted_r1 = r1;
+    ws->lists_raw = false;  // the old lists are about to be overwritten
+    ws->prefilled = true;
+    ws->pre_n = N;
+    ws->pre_tx = tiles_x;
+    ws->pre_ty = tiles_y;
+    ws->pre_r0 = r0;
+    ws->pre_r1 = r1;
     return GI2D_OK;
 }
 
@@ -1130,16 +1181,19 @@ int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int
                              radii, conics, num_tiles_hit);
     if (rc != GI2D_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    int *tile_count = nullptr;
+    bool fill = false;
     if (ws) {
-        rc = begin_fused_count(ws, N, tiles_x, tiles_y, st);
+        rc = begin_prefill(ws, N, tiles_x, tiles_y, st);
         if (rc != GI2D_OK) return rc;
-        tile_count = ws->d_count;
+        fill = ws->prefilled;
     }
     if (N == 0) return GI2D_OK;
     project_cholesky_fwd_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(
         means2d, L_elements, N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii,
-        conics, num_tiles_hit, tile_count, ws ? ws->counted_r0 : 0, ws ? ws->counted_r1 : 0);
+        conics, num_tiles_hit, fill ? ws->d_count : nullptr, fill ? ws->d_seg : nullptr,
+        fill ? ws->seg_cap : 0, fill ? ws->pre_r0 : 0, fill ? ws->pre_r1 : 0,
+        fill ? ws->d_status : nullptr, fill ? ws->h_status_dev : nullptr,
+        fill ? ws->generation : 0);
     return launch_status();
 }
 
@@ -1153,18 +1207,19 @@ int gi2d_project_rs_fwd(const float *means2d, const float *scales, const float *
     if (rc != GI2D_OK) return rc;
     if (N > 0 && !rotation) return GI2D_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    int *tile_count = nullptr;
+    bool fill = false;
     if (ws) {
-        rc = begin_fused_count(ws, N, tiles_x, tiles_y, st);
+        rc = begin_prefill(ws, N, tiles_x, tiles_y, st);
         if (rc != GI2D_OK) return rc;
-        tile_count = ws->d_count;
+        fill = ws->prefilled;
     }
     if (N == 0) return GI2D_OK;
-    project_rs_fwd_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(means2d, scales, rotation, N, H, W,
-                                                       tiles_x, tiles_y, conv->center_bias, xys,
-                                                       depths, radii, conics, num_tiles_hit,
-                                                       tile_count, ws ? ws->counted_r0 : 0,
-                                                       ws ? ws->counted_r1 : 0);
+    project_rs_fwd_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(
+        means2d, scales, rotation, N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths,
+        radii, conics, num_tiles_hit, fill ? ws->d_count : nullptr, fill ? ws->d_seg : nullptr,
+        fill ? ws->seg_cap : 0, fill ? ws->pre_r0 : 0, fill ? ws->pre_r1 : 0,
+        fill ? ws->d_status : nullptr, fill ? ws->h_status_dev : nullptr,
+        fill ? ws->generation : 0);
     return launch_status();
 }
 
@@ -1195,6 +1250,22 @@ int gi2d_project_rs_bwd(const float *means2d, const float *scales, const float *
     return launch_status();
 }
 
+// Fills the lists from xys / radii with the standalone kernel.
+static int launch_bin(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
+                      int tiles_y, int r0, int r1, hipStream_t st)
+{
+    int rc = GI2D_OK;
+    if (ws->counters_dirty) {
+        rc = zero_counters(ws, st);
+        if (rc != GI2D_OK) return rc;
+    }
+    ws->counters_dirty = true;
+    bin_tiles_kernel<<<max(1, cdiv(N, PG_THREADS)), PG_THREADS, 0, st>>>(
+        xys, radii, N, tiles_x, tiles_y, r0, r1, ws->d_count, ws->d_seg, ws->seg_cap,
+        ws->d_status, ws->h_status_dev, ws->generation);
+    return launch_status();
+}
+
 int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
                    int tiles_y, int flags, void *stream)
 {
@@ -1210,92 +1281,82 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     bool sync = (flags & GI2D_BIN_SYNC) != 0;
     bool prev_overflow = false;
 
-    // an earlier asynchronous frame that did not fit: grow for it, tell the caller
+    // an earlier asynchronous frame whose lists did not fit: tell the caller (once)
     if (ws->h_status[2] > ws->overflow_ack) {
         ws->overflow_ack = ws->h_status[2];
         prev_overflow = true;
     }
 
-    bool counted = (flags & GI2D_BIN_COUNTED) && ws->counted && ws->counted_n == N &&
-                   ws->counted_tx == tiles_x && ws->counted_ty == tiles_y &&
-                   ws->counted_r0 == r0 && ws->counted_r1 == r1;
-    if ((flags & GI2D_BIN_COUNTED) && !counted) return GI2D_E_STATE;
-    if (!counted) {
-        if (nogrow && T > ws->tiles_cap) return GI2D_E_CAPACITY;
-        int rc = ensure_tiles(ws, max(1, T));
-        if (rc != GI2D_OK) return rc;
-        if (ws->counters_dirty || ws->counted) {
-            zero_ints_kernel<<<cdiv(ws->tiles_cap * CNT_STRIDE, 256), 256, 0, st>>>(
-                ws->d_count, ws->tiles_cap * CNT_STRIDE);
-            rc = launch_status();
-            if (rc != GI2D_OK) return rc;
-        }
-        ws->counters_dirty = true;
-        if (N > 0) {
-            count_tiles_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(xys, radii, N, tiles_x, tiles_y, r0,
-                                                             r1, ws->d_count);
-            rc = launch_status();
+    bool prefilled = ws->prefilled && ws->pre_n == N && ws->pre_tx == tiles_x &&
+                     ws->pre_ty == tiles_y && ws->pre_r0 == r0 && ws->pre_r1 == r1;
+    ws->prefilled = false;
+    if (!(flags & GI2D_BIN_COUNTED)) prefilled = false;
+
+    if (!prefilled) {
+        // Size the lists.  Steady state needs no synchronisation: the capacity keeps a 2x
+        // margin over the largest per-tile count seen from completed frames.  A new problem
+        // shape says nothing about its counts: learn them once, synchronously.
+        if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1) && !nogrow) sync = true;
+        if (nogrow) {
+            if (T > ws->tiles_cap || ws->seg_cap == 0) return GI2D_E_CAPACITY;
+        } else {
+            int rc = ensure_lists(ws, max(1, T), wanted_cap(ws, sync ? 0 : ws->h_status[0]));
             if (rc != GI2D_OK) return rc;
         }
     }
-    ws->counted = false;
-
-    // Size the lists.  Steady state needs no synchronisation: the capacity keeps a 2x margin
-    // over the largest count seen from completed frames.
-    if (!nogrow) {
-        int64_t seen = ws->h_status[0];
-        // a new problem shape says nothing about its count: learn it once, synchronously
-        if (ws->ids_cap == 0 || N != ws->n_binned || tiles_x != ws->tiles_x ||
-            tiles_y != ws->tiles_y || r0 != ws->bin_row0 || r1 != ws->bin_row1)
-            sync = true;
-        if (!sync && 2 * seen > ws->ids_cap) {
-            int rc = ensure_ids(ws, 2 * seen + 1024);
-            if (rc != GI2D_OK) return rc;
-        }
-    }
-
     ws->generation += 1;
     ws->tiles_x = tiles_x;
     ws->tiles_y = tiles_y;
     ws->n_binned = N;
     ws->bin_row0 = r0;
     ws->bin_row1 = r1;
-    scan_tiles_kernel<<<1, 1024, 0, st>>>(ws->d_count, ws->d_offsets, T,
-                                          sync && !nogrow ? (long long)INT_MAX - 1
-                                                          : (long long)ws->ids_cap,
-                                          ws->d_status, ws->generation);
-    int rc = launch_status();
-    if (rc != GI2D_OK) return rc;
-    ws->counters_dirty = false;  // the scan left the counters at zero
+    if (!prefilled) {
+        int rc = launch_bin(ws, xys, radii, N, tiles_x, tiles_y, r0, r1, st);
+        if (rc != GI2D_OK) return rc;
+    }
+    ws->lists_raw = true;
 
     if (sync) {
-        DevStatus hs;
-        HIP_TRY(hipMemcpyAsync(&hs, ws->d_status, sizeof(hs), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        int64_t total = hs.total;
-        if (total > ws->ids_cap) {
-            if (nogrow) {
-                ws->overflow_ack = ws->generation;  // reported here, not again on the next call
-                return GI2D_E_CAPACITY;
-            }
-            rc = ensure_ids(ws, total + total / 2 + 1024);
+        // finalise now, read the list lengths, and redo the binning if a segment overflowed
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int rc = finalize_lists(ws, st);
             if (rc != GI2D_OK) return rc;
+            int maxlen = 0;
+            if (T > 0) {
+                int *h_len = (int *)malloc(sizeof(int) * (size_t)T);
+                if (!h_len) return (int)hipErrorOutOfMemory;
+                hipError_t e = hipMemcpyAsync(h_len, ws->d_len, sizeof(int) * (size_t)T,
+                                              hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e != hipSuccess) {
+                    free(h_len);
+                    return (int)e;
+                }
+                for (int i = 0; i < T; ++i) maxlen = h_len[i] > maxlen ? h_len[i] : maxlen;
+                free(h_len);
+            } else {
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+            if (maxlen > ws->h_status[0]) ws->h_status[0] = maxlen;
+            const bool fits = maxlen <= ws->seg_cap;
+            if (!fits) ws->overflow_ack = ws->generation;  // reported (or repaired) right here
+            if (nogrow) {
+                if (!fits) return GI2D_E_CAPACITY;
+                break;
+            }
+            // keep the asynchronous policy's 2x margin from the start, so that the next frames
+            // of this shape never have to reallocate
+            const int want = wanted_cap(ws, maxlen);
+            if (want <= ws->seg_cap) break;
+            if (attempt == 1) return GI2D_E_CAPACITY;
+            rc = ensure_lists(ws, max(1, T), want);
+            if (rc != GI2D_OK) return rc;
+            ws->tiles_x = tiles_x;
+            ws->tiles_y = tiles_y;
+            rc = launch_bin(ws, xys, radii, N, tiles_x, tiles_y, r0, r1, st);
+            if (rc != GI2D_OK) return rc;
+            ws->lists_raw = true;
         }
-    }
-    {
-        // always launched: its first lane also publishes the count to the host
-        ws->counters_dirty = true;
-        fill_tiles_kernel<<<max(1, cdiv(N, PG_THREADS)), PG_THREADS, 0, st>>>(
-            xys, radii, N, tiles_x, tiles_y, r0, r1, ws->d_offsets, ws->d_count, ws->d_ids, T,
-            ws->d_status, ws->h_status_dev);
-        rc = launch_status();
-        if (rc != GI2D_OK) return rc;
-    }
-    if (T > 0) {
-        sort_tiles_kernel<<<T, WAVE, 0, st>>>(ws->d_offsets, ws->d_ids, ws->d_count, T);
-        rc = launch_status();
-        if (rc != GI2D_OK) return rc;
-        ws->counters_dirty = false;  // the sort returned every cursor to zero
     }
     return prev_overflow ? GI2D_E_PREV_OVERFLOW : GI2D_OK;
 }
@@ -1303,27 +1364,55 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
 int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_capacity,
                    void *stream)
 {
-    if (!ws || !tile_offsets || ws->generation == 0) return ws ? GI2D_E_STATE : GI2D_E_INVALID;
+    if (!ws || !tile_offsets) return GI2D_E_INVALID;
+    if (ws->generation == 0 || ws->tiles_x == 0) return GI2D_E_STATE;
     DeviceGuard guard(ws->device);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipStreamSynchronize(st));
-    if (ws->h_status[2] == ws->generation) return GI2D_E_CAPACITY;
+    int rc = finalize_lists(ws, st);
+    if (rc != GI2D_OK) return rc;
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
-    HIP_TRY(hipMemcpyAsync(tile_offsets, ws->d_offsets, sizeof(int) * ((size_t)T + 1),
-                           hipMemcpyDefault, st));
-    int64_t total = ws->h_status[0];
-    if (ids && total > 0) {
-        if (total > ids_capacity) return GI2D_E_CAPACITY;
-        HIP_TRY(hipMemcpyAsync(ids, ws->d_ids, sizeof(int) * (size_t)total, hipMemcpyDefault, st));
+    const int C = ws->seg_cap;
+    int *h_len = (int *)malloc(sizeof(int) * ((size_t)T + 1));
+    int *h_off = (int *)malloc(sizeof(int) * ((size_t)T + 1));
+    if (!h_len || !h_off) {
+        free(h_len);
+        free(h_off);
+        return (int)hipErrorOutOfMemory;
     }
-    HIP_TRY(hipStreamSynchronize(st));
-    return GI2D_OK;
+    hipError_t e = hipSuccess;
+    if (T > 0) e = hipMemcpyAsync(h_len, ws->d_len, sizeof(int) * (size_t)T, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    int64_t total = 0;
+    bool over = false;
+    for (int t = 0; t < T && e == hipSuccess; ++t) {
+        h_off[t] = (int)total;
+        if (h_len[t] > C) over = true;
+        total += h_len[t];
+    }
+    h_off[T] = (int)total;
+    rc = GI2D_OK;
+    if (e != hipSuccess) rc = (int)e;
+    else if (over || total >= INT_MAX) rc = GI2D_E_CAPACITY;
+    else if (ids && total > ids_capacity) rc = GI2D_E_CAPACITY;
+    if (rc == GI2D_OK) {
+        e = hipMemcpyAsync(tile_offsets, h_off, sizeof(int) * ((size_t)T + 1), hipMemcpyDefault, st);
+        // compaction: one copy per non-empty tile; a test / diagnostics path, not a hot one
+        for (int t = 0; t < T && e == hipSuccess && ids; ++t)
+            if (h_len[t] > 0)
+                e = hipMemcpyAsync(ids + h_off[t], ws->d_seg + (size_t)t * C,
+                                   sizeof(int) * (size_t)h_len[t], hipMemcpyDefault, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = (int)e;
+    }
+    free(h_len);
+    free(h_off);
+    return rc;
 }
 
 static int check_raster_args(gi2d_workspace *ws, int N, int H, int W, const gi2d_conv *conv)
 {
     if (!ws || !conv || N < 0 || H < 1 || W < 1) return GI2D_E_INVALID;
-    if (ws->generation == 0) return GI2D_E_STATE;
+    if (ws->generation == 0 || ws->tiles_x == 0) return GI2D_E_STATE;
     if (ws->tiles_x != cdiv(W, GI2D_BLOCK) || ws->tiles_y != cdiv(H, GI2D_BLOCK) ||
         ws->n_binned != N)
         return GI2D_E_STATE;
@@ -1337,22 +1426,34 @@ int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *co
 {
     int rc = check_raster_args(ws, N, H, W, conv);
     if (rc != GI2D_OK) return rc;
-    if (ws->tiles_x * (ws->bin_row1 - ws->bin_row0) == 0) return GI2D_OK;  // empty band
-    if (!out_img || (N > 0 && (!xys || !conics || !colors || !opacity))) return GI2D_E_INVALID;
-    if (conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     DeviceGuard guard(ws->device);
     hipStream_t st = (hipStream_t)stream;
+    if (T == 0) {  // empty band
+        ws->lists_raw = false;
+        return GI2D_OK;
+    }
+    if (!out_img || (N > 0 && (!xys || !conics || !colors || !opacity))) return GI2D_E_INVALID;
+    if (conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
     float bg[3] = {0.f, 0.f, 0.f};
     if (conv->bg_weight != 0.0f) {
         // three floats, needed as kernel arguments
         HIP_TRY(hipMemcpyAsync(bg, background, sizeof(bg), hipMemcpyDefault, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
-    if (T == 0) return GI2D_OK;
-    rasterize_sum_fwd_kernel<<<T, 256, 0, st>>>(ws->d_offsets, ws->d_ids, xys, conics, colors,
-                                                opacity, bg[0], bg[1], bg[2], H, W, ws->tiles_x,
-                                                ws->bin_row0, T, *conv, ws->cull, out_img);
+    if (ws->lists_raw) {
+        rasterize_sum_fwd_kernel<true><<<T, 256, 0, st>>>(
+            ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, conics, colors, opacity, bg[0],
+            bg[1], bg[2], H, W, ws->tiles_x, ws->bin_row0, T, *conv, ws->cull, ws->d_status,
+            ws->generation, out_img);
+        ws->lists_raw = false;
+        ws->counters_dirty = false;
+    } else {
+        rasterize_sum_fwd_kernel<false><<<T, 256, 0, st>>>(
+            ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, conics, colors, opacity, bg[0],
+            bg[1], bg[2], H, W, ws->tiles_x, ws->bin_row0, T, *conv, ws->cull, ws->d_status,
+            ws->generation, out_img);
+    }
     return launch_status();
 }
 
@@ -1364,19 +1465,22 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
     int rc = check_raster_args(ws, N, H, W, conv);
     if (rc != GI2D_OK) return rc;
     if (N == 0) return GI2D_OK;
-    const bool empty_band = ws->tiles_x * (ws->bin_row1 - ws->bin_row0) == 0;
-    if (!xys || !radii || !conics || !colors || !opacity || (!v_out && !empty_band) || !v_xys ||
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (!xys || !radii || !conics || !colors || !opacity || (!v_out && T > 0) || !v_xys ||
         !v_conics || !v_colors || !v_opacity)
         return GI2D_E_INVALID;
     DeviceGuard guard(ws->device);
     hipStream_t st = (hipStream_t)stream;
-    if (ws->part_cap < ws->ids_cap) {
+    rc = finalize_lists(ws, st);
+    if (rc != GI2D_OK) return rc;
+    const int64_t slots = (int64_t)ws->tiles_cap * ws->seg_cap;
+    if (ws->part_slots < slots) {
         HIP_TRY(hipDeviceSynchronize());
         if (ws->d_partials) (void)hipFree(ws->d_partials);
         ws->d_partials = nullptr;
-        ws->part_cap = 0;
-        HIP_TRY(hipMalloc(&ws->d_partials, sizeof(float) * PART_STRIDE * (size_t)ws->ids_cap));
-        ws->part_cap = ws->ids_cap;
+        ws->part_slots = 0;
+        HIP_TRY(hipMalloc(&ws->d_partials, sizeof(float) * PART_STRIDE * (size_t)slots));
+        ws->part_slots = slots;
     }
     if (ws->slot_cap < N) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1387,19 +1491,67 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
         HIP_TRY(hipMemset(ws->d_slot_tab, 0, sizeof(int) * SLOT_TAB * (size_t)N));
         ws->slot_cap = N;
     }
-    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (T > 0) {
         rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(
-            ws->d_offsets, ws->d_ids, xys, radii, conics, colors, opacity, H, W, ws->tiles_x,
-            ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull, v_out, ws->d_partials,
-            ws->d_slot_tab);
+            ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, colors, opacity, H, W,
+            ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull, v_out,
+            ws->d_partials, ws->d_slot_tab);
         rc = launch_status();
         if (rc != GI2D_OK) return rc;
     }
     gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(
-        xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, ws->d_offsets,
-        ws->d_ids, ws->d_partials, ws->d_slot_tab, v_xys, v_conics, v_colors, v_opacity);
+        xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, ws->d_len, ws->d_seg,
+        ws->seg_cap, ws->d_partials, ws->d_slot_tab, v_xys, v_conics, v_colors, v_opacity);
     return launch_status();
+}
+
+// One call per frame: projection (filling the lists), binning bookkeeping, rasterisation.
+static int render_tail(gi2d_workspace *ws, int N, int H, int W, int tiles_x, int tiles_y,
+                       const gi2d_conv *conv, const float *xys, const int *radii,
+                       const float *conics, const float *colors, const float *opacity,
+                       const float *background, float *out_img, void *ev_begin, void *ev_end,
+                       void *stream)
+{
+    int rc = gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
+    if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
+    const int late = rc;
+    if (ev_begin) HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, (hipStream_t)stream));
+    rc = gi2d_rasterize_sum_fwd(ws, xys, conics, colors, opacity, background, N, H, W, conv,
+                                out_img, stream);
+    if (rc != GI2D_OK) return rc;
+    if (ev_end) HIP_TRY(hipEventRecord((hipEvent_t)ev_end, (hipStream_t)stream));
+    return late;
+}
+
+int gi2d_render_cholesky_fwd(gi2d_workspace *ws, const float *means2d, const float *L_elements,
+                             const float *colors, const float *opacity, const float *background,
+                             int N, int H, int W, const gi2d_conv *conv, float *xys, float *depths,
+                             int *radii, float *conics, int *num_tiles_hit, float *out_img,
+                             void *raster_begin_event, void *raster_end_event, void *stream)
+{
+    if (!ws) return GI2D_E_INVALID;
+    const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
+    int rc = gi2d_project_cholesky_fwd(means2d, L_elements, N, H, W, tiles_x, tiles_y, conv, xys,
+                                       depths, radii, conics, num_tiles_hit, ws, stream);
+    if (rc != GI2D_OK) return rc;
+    return render_tail(ws, N, H, W, tiles_x, tiles_y, conv, xys, radii, conics, colors, opacity,
+                       background, out_img, raster_begin_event, raster_end_event, stream);
+}
+
+int gi2d_render_rs_fwd(gi2d_workspace *ws, const float *means2d, const float *scales,
+                       const float *rotation, const float *colors, const float *opacity,
+                       const float *background, int N, int H, int W, const gi2d_conv *conv,
+                       float *xys, float *depths, int *radii, float *conics, int *num_tiles_hit,
+                       float *out_img, void *raster_begin_event, void *raster_end_event,
+                       void *stream)
+{
+    if (!ws) return GI2D_E_INVALID;
+    const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
+    int rc = gi2d_project_rs_fwd(means2d, scales, rotation, N, H, W, tiles_x, tiles_y, conv, xys,
+                                 depths, radii, conics, num_tiles_hit, ws, stream);
+    if (rc != GI2D_OK) return rc;
+    return render_tail(ws, N, H, W, tiles_x, tiles_y, conv, xys, radii, conics, colors, opacity,
+                       background, out_img, raster_begin_event, raster_end_event, stream);
 }
 
 int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,

@@ -67,6 +67,7 @@ class Workspace:
         self.key = None       # identity of the tensors the current lists were built from
         self.keep = None      # strong references: keeps their storage from being recycled
         self.counted_key = None
+        self.rows = (0, 2 ** 31 - 1)
         self.sync_binning = os.environ.get("GI2D_SYNC", "0") == "1"
 
     def __del__(self):
@@ -80,17 +81,14 @@ class Workspace:
     def info(self):
         arr = (ctypes.c_int64 * 8)()
         check(lib.gi2d_workspace_info(self.handle, arr), "gi2d_workspace_info")
-        return dict(capacity=arr[0], intersections=arr[1], generation=arr[2], tiles_x=arr[3],
+        return dict(capacity=arr[0], max_tile_count=arr[1], generation=arr[2], tiles_x=arr[3],
                     tiles_y=arr[4], num_gaussians=arr[5], row_begin=arr[6], row_end=arr[7])
-
-    def reserve(self, max_intersections, max_tiles=0):
-        check(lib.gi2d_workspace_reserve(self.handle, int(max_intersections), int(max_tiles)),
-              "gi2d_workspace_reserve")
 
     def set_rows(self, row_begin=0, row_end=2 ** 31 - 1):
         """Restricts binning/rasterisation to tile rows [row_begin, row_end) (a band)."""
         check(lib.gi2d_workspace_set_rows(self.handle, int(row_begin), int(row_end)),
               "gi2d_workspace_set_rows")
+        self.rows = (int(row_begin), int(row_end))
         self.key = None
         self.counted_key = None
 
@@ -123,17 +121,21 @@ class Workspace:
         self.key = key
         self.keep = (xys, radii)
 
+    def reserve(self, per_tile_capacity, max_tiles=0):
+        check(lib.gi2d_workspace_reserve(self.handle, int(per_tile_capacity), int(max_tiles)),
+              "gi2d_workspace_reserve")
+
     def bins(self):
         """(tile_offsets, ids) of the current lists as CPU int32 tensors (synchronises)."""
         inf = self.info()
         T = inf["tiles_x"] * (inf["row_end"] - inf["row_begin"])
-        torch.cuda.synchronize(self.device)
-        inf = self.info()
-        total = max(int(inf["intersections"]), 0)
+        st = _stream(self.device)
         offs = torch.empty(T + 1, dtype=torch.int32, device=self.device)
+        check(lib.gi2d_copy_bins(self.handle, _ptr(offs), None, 0, st), "gi2d_copy_bins")
+        total = int(offs[-1].item())
         ids = torch.empty(max(total, 1), dtype=torch.int32, device=self.device)
-        check(lib.gi2d_copy_bins(self.handle, _ptr(offs), _ptr(ids), ids.numel(),
-                                 _stream(self.device)), "gi2d_copy_bins")
+        check(lib.gi2d_copy_bins(self.handle, _ptr(offs), _ptr(ids), ids.numel(), st),
+              "gi2d_copy_bins")
         return offs.cpu(), ids[:total].cpu()
 
 

@@ -53,8 +53,7 @@ class FramePipeline:
         self._set_rows()
 
     def _set_rows(self):
-        check(lib.gi2d_workspace_set_rows(self.ws.handle, self.rows[0], self.rows[1]),
-              "gi2d_workspace_set_rows")
+        self.ws.set_rows(self.rows[0], self.rows[1])
 
     # -- forward ---------------------------------------------------------------------------
     def project(self, means, cov_a, cov_b=None):
@@ -88,12 +87,35 @@ class FramePipeline:
               "gi2d_rasterize_sum_fwd")
         return out
 
-    def forward(self, means, cov_a, cov_b, colors, opacity):
-        """project -> bin -> rasterize; returns the (band of the) image, ``[band_h, W, 3]``."""
-        self._set_rows()
-        self.project(means, cov_a, cov_b)
-        self.bin()
-        return self.rasterize(colors, opacity)
+    def forward(self, means, cov_a, cov_b, colors, opacity, out=None, events=None):
+        """project -> bin -> rasterize in one C call; returns the (band of the) image,
+        ``[band_h, W, 3]``.  ``events``: optional pair of ``torch.cuda.Event`` recorded right
+        before / after the rasterize launch."""
+        out = self.image if out is None else out
+        if self.rows_dirty():
+            self._set_rows()
+        ev0 = ev1 = None
+        if events is not None:
+            for e in events:  # a torch event has no handle until it is first recorded
+                if not e.cuda_event:
+                    e.record()
+            ev0, ev1 = (ctypes.c_void_p(e.cuda_event) for e in events)
+        common = (_ptr(colors), _ptr(opacity), _ptr(self.background), self.N, self.H, self.W,
+                  ctypes.byref(self.conv), _ptr(self.xys), _ptr(self.depths), _ptr(self.radii),
+                  _ptr(self.conics), _ptr(self.num_tiles_hit), _ptr(out), ev0, ev1,
+                  _stream(self.device))
+        if self.kind == "cholesky":
+            rc = lib.gi2d_render_cholesky_fwd(self.ws.handle, _ptr(means), _ptr(cov_a), *common)
+        else:
+            rc = lib.gi2d_render_rs_fwd(self.ws.handle, _ptr(means), _ptr(cov_a), _ptr(cov_b),
+                                        *common)
+        check(rc, "gi2d_render_%s_fwd" % self.kind)
+        self.ws.key = None
+        return out
+
+    def rows_dirty(self):
+        """True when another user of the (shared) workspace may have changed its tile rows."""
+        return self.ws.rows != self.rows
 
     # -- backward --------------------------------------------------------------------------
     def _alloc_backward(self, cov_a, cov_b):
@@ -132,5 +154,4 @@ class FramePipeline:
 
     def intersections(self):
         """Number of (tile, Gaussian) intersections of the last binning (synchronises)."""
-        torch.cuda.synchronize(self.device)
-        return int(self.ws.info()["intersections"])
+        return int(self.ws.bins()[0][-1])

@@ -127,12 +127,7 @@ class ShardedFrame:
     def render_band(self, means, cov_a, cov_b, colors, opacity):
         """Renders this rank's band into the current gather slot."""
         band = self.gather.band_view()
-        self.pipe._set_rows()
-        self.pipe.project(means, cov_a, cov_b)
-        self.pipe.bin()
-        if band.shape[0]:
-            self.pipe.rasterize(colors, opacity, out=band)
-        return band
+        return self.pipe.forward(means, cov_a, cov_b, colors, opacity, out=band)
 
     def render(self, means, cov_a, cov_b, colors, opacity, async_op=False):
         """Band render plus the all-gather; returns ``(image[H,W,3], work)``."""
@@ -170,7 +165,8 @@ def bench_tile_row_sharded(device, rank, world, steps=50, warmup=5, workload="uh
         for _ in range(steps):
             fn()
         sync()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                         device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) / steps
 

@@ -29,13 +29,14 @@ extern "C" {
 #define GI2D_OK 0
 #define GI2D_E_INVALID (-1)       /* bad pointer / size / unsupported block size           */
 #define GI2D_E_STATE (-2)         /* e.g. rasterize before any bin_tiles on this workspace  */
-#define GI2D_E_CAPACITY (-3)      /* intersections exceed the reserved list capacity        */
-#define GI2D_E_PREV_OVERFLOW (-4) /* an EARLIER asynchronous frame overflowed (its image is */
-                                  /* NaN); the workspace has been grown, call again         */
+#define GI2D_E_CAPACITY (-3)      /* a tile's list exceeds the reserved per-tile capacity   */
+#define GI2D_E_PREV_OVERFLOW (-4) /* an EARLIER asynchronous frame overflowed a tile list   */
+                                  /* (those tiles of its image are NaN); the workspace has  */
+                                  /* been grown, call again                                 */
 
 /* flags of gi2d_bin_tiles */
-#define GI2D_BIN_SYNC 1    /* wait for the intersection count and size the lists exactly     */
-#define GI2D_BIN_COUNTED 2 /* per-tile counts were already accumulated by gi2d_project_*_fwd */
+#define GI2D_BIN_SYNC 1    /* wait for the list lengths and size the lists to fit            */
+#define GI2D_BIN_COUNTED 2 /* the lists were already filled by gi2d_project_*_fwd(ws)        */
 #define GI2D_BIN_NOGROW 4  /* never reallocate (fixed-memory callers)                        */
 
 /* Conventions the reference cannot settle (its operator source is absent);
@@ -54,13 +55,15 @@ int gi2d_version(void);
 const char *gi2d_error_string(int status);
 void gi2d_default_conv(gi2d_conv *conv);
 
-/* Workspace: owns the per-tile counters, offsets, Gaussian-id lists and the
- * backward partial-sum slab, so that the three raster passes of
- * GaussianImage_Cholesky.forward() (gaussianimage_cholesky.py:81,89,95) share
- * one binning and no call needs a host synchronisation in steady state. */
+/* Workspace: owns the per-tile counters, the Gaussian-id lists (one fixed-
+ * capacity segment per tile) and the backward partial-sum slab, so that the
+ * three raster passes of GaussianImage_Cholesky.forward()
+ * (gaussianimage_cholesky.py:81,89,95) share one binning and no call needs a
+ * host synchronisation in steady state.  gi2d_workspace_reserve pre-allocates
+ * room for max_tiles tiles of per_tile_capacity ids each. */
 int gi2d_workspace_create(int device, gi2d_workspace **out);
 int gi2d_workspace_destroy(gi2d_workspace *ws);
-int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t max_intersections, int max_tiles);
+int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int max_tiles);
 /* Options: GI2D_OPT_CULL (default 1) lets the backward skip pixels outside a
  * Gaussian's support rectangle; 0 evaluates every pixel of every listed tile
  * (same results, used by the tests to prove that). */
@@ -72,15 +75,15 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value);
  * the partition of the tile-row sharding across GPUs; it has no counterpart
  * in the single-GPU reference. */
 int gi2d_workspace_set_rows(gi2d_workspace *ws, int row_begin, int row_end);
-/* info[0]=list capacity, [1]=intersections of the last COMPLETED binning,
- * [2]=binning generation, [3]=tiles_x, [4]=tiles_y, [5]=Gaussians binned,
+/* info[0]=per-tile list capacity, [1]=largest per-tile count published by
+ * completed frames, [2]=binning generation, [3]=tiles_x, [4]=tiles_y, [5]=Gaussians binned,
  * [6],[7]=tile rows [begin,end) of the current lists */
 int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[8]);
 
 /* project_gaussians_2d(means2d, L_elements, H, W, tile_bounds)
  * (gaussianimage_cholesky.py:77).  Outputs xys[N,2], depths[N], radii[N],
- * conics[N,3], num_tiles_hit[N].  With ws != NULL the per-tile counts of the
- * binning are accumulated in the same launch (then pass GI2D_BIN_COUNTED). */
+ * conics[N,3], num_tiles_hit[N].  With ws != NULL the tile lists of the
+ * binning are filled in the same launch (then pass GI2D_BIN_COUNTED). */
 int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int N, int H, int W,
                               int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
                               float *depths, int *radii, float *conics, int *num_tiles_hit,
@@ -109,8 +112,9 @@ int gi2d_project_rs_bwd(const float *means2d, const float *scales, const float *
 int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
                    int tiles_y, int flags, void *stream);
 
-/* Copies the current lists out (device or host destinations): tile_offsets
- * gets tiles+1 ints, ids up to ids_capacity ints.  Synchronises the stream. */
+/* Copies the current lists out in compact form (device or host destinations):
+ * tile_offsets gets tiles+1 ints (exclusive scan of the list lengths), ids
+ * (may be NULL) tile_offsets[tiles] ints.  Synchronises the stream. */
 int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_capacity,
                    void *stream);
 
@@ -130,6 +134,23 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
                            const float *conics, const float *colors, const float *opacity, int N,
                            int H, int W, const gi2d_conv *conv, const float *v_out, float *v_xys,
                            float *v_conics, float *v_colors, float *v_opacity, void *stream);
+
+/* One call per frame: gi2d_project_*_fwd (filling the lists) + gi2d_bin_tiles +
+ * gi2d_rasterize_sum_fwd on the workspace's current tile rows; the forward of
+ * gaussianimage_cholesky.py:77-82 / gaussianimage_rs.py:75-77 without the
+ * Python between the operators.  raster_*_event: optional hipEvent_t recorded
+ * on `stream` right before / after the rasterize launch (instrumentation). */
+int gi2d_render_cholesky_fwd(gi2d_workspace *ws, const float *means2d, const float *L_elements,
+                             const float *colors, const float *opacity, const float *background,
+                             int N, int H, int W, const gi2d_conv *conv, float *xys, float *depths,
+                             int *radii, float *conics, int *num_tiles_hit, float *out_img,
+                             void *raster_begin_event, void *raster_end_event, void *stream);
+int gi2d_render_rs_fwd(gi2d_workspace *ws, const float *means2d, const float *scales,
+                       const float *rotation, const float *colors, const float *opacity,
+                       const float *background, int N, int H, int W, const gi2d_conv *conv,
+                       float *xys, float *depths, int *radii, float *conics, int *num_tiles_hit,
+                       float *out_img, void *raster_begin_event, void *raster_end_event,
+                       void *stream);
 
 /* Adan optimizer step for the parameter tensors of the fitted image, the step
  * that follows the path in every training iteration
