@@ -106,15 +106,17 @@ def bench_forward(pipe, inputs, steps, warmup, sync_all):
     for a, b in ev:  # give every event its handle outside the timed region
         a.record()
         b.record()
+    run = pipe.bind(means, cov_a, cov_b, col, op)
     for _ in range(warmup):
-        pipe.forward(means, cov_a, cov_b, col, op)
+        run()
     sync_all()
     t0 = time.perf_counter()
     for k in range(steps):
-        pipe.forward(means, cov_a, cov_b, col, op, events=ev[k])
+        # every 4th frame is bracketed: an event pair costs the GPU ~2 us of its own
+        run(ev[k] if k % 4 == 0 else None)
     sync_all()
     el = time.perf_counter() - t0
-    raster_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    raster_ms = sorted(a.elapsed_time(b) for a, b in ev[::4])
     return el, raster_ms
 
 

@@ -113,6 +113,37 @@ class FramePipeline:
         self.ws.key = None
         return out
 
+    def bind(self, means, cov_a, cov_b, colors, opacity, out=None):
+        """Pre-builds the argument list of the per-frame call for a fixed set of tensors and
+        returns ``run(events=None)``: the same as ``forward`` without the per-call Python work
+        (for render loops over persistent buffers).  The tensors must stay alive and in place."""
+        out = self.image if out is None else out
+        keep = (means, cov_a, cov_b, colors, opacity, out)
+        tail = (_ptr(colors), _ptr(opacity), _ptr(self.background), self.N, self.H, self.W,
+                ctypes.byref(self.conv), _ptr(self.xys), _ptr(self.depths), _ptr(self.radii),
+                _ptr(self.conics), _ptr(self.num_tiles_hit), _ptr(out))
+        if self.kind == "cholesky":
+            fn, head = lib.gi2d_render_cholesky_fwd, (self.ws.handle, _ptr(means), _ptr(cov_a))
+        else:
+            fn, head = lib.gi2d_render_rs_fwd, (self.ws.handle, _ptr(means), _ptr(cov_a),
+                                                _ptr(cov_b))
+        stream = _stream(self.device)
+        ws, rows, name = self.ws, self.rows, "gi2d_render_%s_fwd" % self.kind
+
+        def run(events=None, _keep=keep):
+            if ws.rows != rows:
+                ws.set_rows(*rows)
+            if events is None:
+                rc = fn(*head, *tail, None, None, stream)
+            else:
+                rc = fn(*head, *tail, events[0].cuda_event, events[1].cuda_event, stream)
+            if rc:
+                check(rc, name)
+            ws.key = None
+            return out
+
+        return run
+
     def rows_dirty(self):
         """True when another user of the (shared) workspace may have changed its tile rows."""
         return self.ws.rows != self.rows
