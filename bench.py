@@ -182,6 +182,27 @@ def bench_model_loops(name, device, steps):
     return out
 
 
+def bench_fused_fit(name, device, steps):
+    """The fused fitting iteration (gaussianimage_amd/fit.py): forward, L2 loss, backward and
+    Adan step in four launches on the raw parameters, no host synchronisation inside the loop."""
+    from gaussianimage_amd import synth
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N, kind, _ = WORKLOADS[name]
+    torch.manual_seed(1)
+    fit = FusedFitter(N, H, W, kind=kind, device=device, keep_image=False)
+    gt = synth.target_image(H, W).to(device)
+    for _ in range(10):
+        fit.step(gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fit.step(gt)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"fused_train_step_ms": ms, "fused_train_iters_per_s": 1e3 / ms,
+            "fused_train_psnr_after_%d_iters" % (steps + 10): fit.psnr()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,6 +313,7 @@ def main():
         pairs = I * 256
         ex["pair_evals_per_s"] = pairs / (raster_avg_ms * 1e-3)
         ex.update(bench_model_loops(args.workload, device, k))
+        ex.update(bench_fused_fit(args.workload, device, max(k, 100)))
         result["extras"] = ex
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         result["cpu_baseline"] = time_cpu_oracle(args.workload)

@@ -71,6 +71,10 @@ SIGNATURES = {
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_render_rs_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gi2d_fit_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp, _vp,
+                              _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gi2d_fit_backward_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(AdanHyper), _vp]),
     "gi2d_adan_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(AdanHyper), _vp,
                             _vp]),
     "gi2d_rasterize_sum_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,

@@ -186,6 +186,9 @@ __device__ __forceinline__ void project_tail(int g, float mx, float my, float sx
         emit_tiles(g, box, row0, row1, tiles_x, tile_count, seg, C);
 }
 
+// RAW = the model's raw parameters come in and its activations are applied here:
+// means = tanh(_xyz), L = _cholesky + (0.5, 0, 0.5) (gaussianimage_cholesky.py:62,74,42).
+template <bool RAW>
 __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
     const float *__restrict__ means, const float *__restrict__ L, int N, int H, int W, int tiles_x,
     int tiles_y, float center_bias, float *__restrict__ xys, float *__restrict__ depths,
@@ -197,14 +200,23 @@ __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
     if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
     if (g >= N) return;
     float l11 = L[3 * g], l21 = L[3 * g + 1], l22 = L[3 * g + 2];
+    float mx = means[2 * g], my = means[2 * g + 1];
+    if (RAW) {
+        mx = tanhf(mx);
+        my = tanhf(my);
+        l11 = l11 + 0.5f;
+        l22 = l22 + 0.5f;
+    }
     float sxx = l11 * l11;
     float sxy = l11 * l21;
     float syy = l21 * l21 + l22 * l22;
-    project_tail(g, means[2 * g], means[2 * g + 1], sxx, sxy, syy, H, W, tiles_x, tiles_y,
-                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count, seg, C, row0,
-                 row1);
+    project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths, radii,
+                 conics, num_tiles_hit, tile_count, seg, C, row0, row1);
 }
 
+// RAW: means = tanh(_xyz), scales = |_scaling + 0.5|, rotation = sigmoid(_rotation) * 2 * pi
+// (gaussianimage_rs.py:55-64).
+template <bool RAW>
 __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     const float *__restrict__ means, const float *__restrict__ scales,
     const float *__restrict__ rot, int N, int H, int W, int tiles_x, int tiles_y,
@@ -216,16 +228,24 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
     if (g >= N) return;
-    float s, c;
-    sincosf(rot[g], &s, &c);
+    float theta = rot[g];
     float s1 = scales[2 * g], s2 = scales[2 * g + 1];
+    float mx = means[2 * g], my = means[2 * g + 1];
+    if (RAW) {
+        mx = tanhf(mx);
+        my = tanhf(my);
+        s1 = fabsf(s1 + 0.5f);
+        s2 = fabsf(s2 + 0.5f);
+        theta = (1.0f / (1.0f + expf(-theta))) * 2.0f * 3.14159274f;
+    }
+    float s, c;
+    sincosf(theta, &s, &c);
     float q1 = s1 * s1, q2 = s2 * s2;
     float sxx = c * c * q1 + s * s * q2;
     float sxy = c * s * (q1 - q2);
     float syy = s * s * q1 + c * c * q2;
-    project_tail(g, means[2 * g], means[2 * g + 1], sxx, sxy, syy, H, W, tiles_x, tiles_y,
-                 center_bias, xys, depths, radii, conics, num_tiles_hit, tile_count, seg, C, row0,
-                 row1);
+    project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths, radii,
+                 conics, num_tiles_hit, tile_count, seg, C, row0, row1);
 }
 
 // Binning from caller-made xys / radii (no projection in front of it).
@@ -512,13 +532,18 @@ __device__ __forceinline__ int xcd_tile(int bid, int T)
 
 #define FWD_LDS_INTS 2816  // 11 KB of LDS: the staging records, or the sort buffer of a long list
 
-template <bool FINALIZE>
+// L2 = true adds the fitting loop's epilogue (gaussianimage_cholesky.py:83-85,104 with
+// utils.py:24-25): clamp to [0,1], L2 loss against the target (stored [3,H,W] like the model's
+// gt_image), and the gradient of the mean-squared error with respect to the unclamped image
+// written to `v_img` [H,W,3]; each tile leaves its sum of squared errors in loss_part[tile].
+template <bool FINALIZE, bool L2>
 __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, float bg0, float bg1, float bg2, int H, int W, int tiles_x,
     int row0, int T, gi2d_conv cv, int cull, DevStatus *status, long long generation,
-    float *__restrict__ out)
+    float *__restrict__ out, const float *__restrict__ gt, float *__restrict__ v_img,
+    float *__restrict__ loss_part)
 {
     __shared__ __attribute__((aligned(16))) int smem[FWD_LDS_INTS];
     float4 *s_a = reinterpret_cast<float4 *>(smem);         // gx, gy, -0.5*a*log2e, -b*log2e
@@ -624,11 +649,36 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     g = g + cv.bg_weight * bg1;
     b = b + cv.bg_weight * bg2;
     if (n_raw > C) r = g = b = __builtin_nanf("");  // overflowed segment: never silently wrong
-    if (inside) {
-        float *o = out + 3 * ((size_t)(i - row0 * GI2D_BLOCK) * W + j);
+    const size_t pix = (size_t)(i - row0 * GI2D_BLOCK) * W + j;
+    if (inside && out != nullptr) {
+        float *o = out + 3 * pix;
         o[0] = r;
         o[1] = g;
         o[2] = b;
+    }
+    if (L2) {
+        float sq = 0.f;
+        if (inside) {
+            const size_t plane = (size_t)H * W, gp = (size_t)i * W + j;
+            const float scale = 2.0f / (3.0f * (float)plane);
+            const float v[3] = {r, g, b};
+            float *vo = v_img + 3 * pix;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float x = v[ch];
+                const float d = fminf(fmaxf(x, 0.f), 1.f) - gt[ch * plane + gp];
+                sq = __builtin_fmaf(d, d, sq);
+                vo[ch] = (x >= 0.f && x <= 1.f) ? scale * d : 0.f;  // clamp passes its interior
+            }
+        }
+        // tile sum in a fixed order: lanes of a wave by DPP, the four waves through LDS
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) sq += __shfl_xor(sq, d);
+        __syncthreads();
+        float *s_red = reinterpret_cast<float *>(smem);
+        if (lane == 0) s_red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) loss_part[t] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     }
 }
 
@@ -753,6 +803,69 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     }
 }
 
+// Adds up Gaussian g's slots of the partial-sum slab, in the row-major order of its tile box.
+__device__ __forceinline__ void gather_partials(int g, int r, float cx, float cy, int tiles_x,
+                                                int tiles_y, int row0, int row1,
+                                                const int *__restrict__ tile_len,
+                                                const int *__restrict__ seg, int C,
+                                                const float *__restrict__ partials,
+                                                const int *__restrict__ slot_tab,
+                                                float acc[PART_STRIDE])
+{
+#pragma unroll
+    for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
+    const int4 tab = *reinterpret_cast<const int4 *>(slot_tab + (size_t)g * SLOT_TAB);
+    if (r <= 0) return;
+    TileBox box = tile_box(cx, cy, (float)r, tiles_x, tiles_y);
+    const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
+    const int w = box.x1 - box.x0;
+    const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
+    // The first SLOT_TAB tiles: list position remembered by pass 1; the loads of the four
+    // slots are independent of each other.
+    int tl[SLOT_TAB], ln[SLOT_TAB];
+    const int pos[SLOT_TAB] = {tab.x, tab.y, tab.z, tab.w};
+#pragma unroll
+    for (int k = 0; k < SLOT_TAB; ++k) {
+        const int ty = w > 0 ? y0 + k / w : 0, tx = w > 0 ? box.x0 + k % w : 0;
+        tl[k] = k < cnt ? (ty - row0) * tiles_x + tx : 0;
+        ln[k] = k < cnt ? tile_len[tl[k]] : 0;
+    }
+    float part[SLOT_TAB][PART_STRIDE];
+#pragma unroll
+    for (int k = 0; k < SLOT_TAB; ++k) {
+        // an overflowed tile (ln > C) wrote no partial sums
+        const bool live = k < cnt && ln[k] <= C && pos[k] >= 0 && pos[k] < ln[k];
+        const float *src = partials + ((size_t)tl[k] * C + (live ? pos[k] : 0)) * PART_STRIDE;
+#pragma unroll
+        for (int u = 0; u < PART_STRIDE; ++u) part[k][u] = live ? src[u] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < SLOT_TAB; ++k)
+#pragma unroll
+        for (int u = 0; u < PART_STRIDE; ++u) acc[u] += part[k][u];
+    // larger boxes: the rest by binary search (lists ascend in Gaussian id)
+    for (int k = SLOT_TAB; k < cnt; ++k) {
+        const int ty = y0 + k / w, tx = box.x0 + k % w;
+        const int t = (ty - row0) * tiles_x + tx;
+        const int n = tile_len[t];
+        if (n > C) continue;
+        const int *lst = seg + (size_t)t * C;
+        int lo = 0, hi = n;
+        while (lo < hi) {  // first position with id >= g
+            int mid = (lo + hi) >> 1;
+            if (lst[mid] < g)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        if (lo < n && lst[lo] == g) {
+            const float *src = partials + ((size_t)t * C + lo) * PART_STRIDE;
+#pragma unroll
+            for (int u = 0; u < PART_STRIDE; ++u) acc[u] += src[u];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_grads_kernel(
     const float *__restrict__ xys, const int *__restrict__ radii, int N, int tiles_x, int tiles_y,
     int row0, int row1, const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
@@ -763,61 +876,8 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     float acc[PART_STRIDE];
-#pragma unroll
-    for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
-    const int r = radii[g];
-    const float cx = xys[2 * g], cy = xys[2 * g + 1];
-    const int4 tab = *reinterpret_cast<const int4 *>(slot_tab + (size_t)g * SLOT_TAB);
-    if (r > 0) {
-        TileBox box = tile_box(cx, cy, (float)r, tiles_x, tiles_y);
-        const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
-        const int w = box.x1 - box.x0;
-        const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
-        // Tiles of the box in row-major order.  The first SLOT_TAB: list position remembered by
-        // pass 1; the loads of the four slots are independent of each other.
-        int tl[SLOT_TAB], ln[SLOT_TAB];
-        const int pos[SLOT_TAB] = {tab.x, tab.y, tab.z, tab.w};
-#pragma unroll
-        for (int k = 0; k < SLOT_TAB; ++k) {
-            const int ty = w > 0 ? y0 + k / w : 0, tx = w > 0 ? box.x0 + k % w : 0;
-            tl[k] = k < cnt ? (ty - row0) * tiles_x + tx : 0;
-            ln[k] = k < cnt ? tile_len[tl[k]] : 0;
-        }
-        float part[SLOT_TAB][PART_STRIDE];
-#pragma unroll
-        for (int k = 0; k < SLOT_TAB; ++k) {
-            // an overflowed tile (ln > C) wrote no partial sums
-            const bool live = k < cnt && ln[k] <= C && pos[k] >= 0 && pos[k] < ln[k];
-            const float *src = partials + ((size_t)tl[k] * C + (live ? pos[k] : 0)) * PART_STRIDE;
-#pragma unroll
-            for (int u = 0; u < PART_STRIDE; ++u) part[k][u] = live ? src[u] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < SLOT_TAB; ++k)
-#pragma unroll
-            for (int u = 0; u < PART_STRIDE; ++u) acc[u] += part[k][u];
-        // larger boxes: the rest by binary search
-        for (int k = SLOT_TAB; k < cnt; ++k) {
-            const int ty = y0 + k / w, tx = box.x0 + k % w;
-            const int t = (ty - row0) * tiles_x + tx;
-            const int n = tile_len[t];
-            if (n > C) continue;
-            const int *lst = seg + (size_t)t * C;
-            int lo = 0, hi = n;
-            while (lo < hi) {  // first position with id >= g
-                int mid = (lo + hi) >> 1;
-                if (lst[mid] < g)
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            if (lo < n && lst[lo] == g) {
-                const float *src = partials + ((size_t)t * C + lo) * PART_STRIDE;
-#pragma unroll
-                for (int u = 0; u < PART_STRIDE; ++u) acc[u] += src[u];
-            }
-        }
-    }
+    gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
+                    tile_len, seg, C, partials, slot_tab, acc);
     v_xy[2 * g] = acc[0];
     v_xy[2 * g + 1] = acc[1];
     v_conic[3 * g] = acc[2];
@@ -853,6 +913,115 @@ struct AdanScalars {
     int no_prox, first_step;
 };
 
+// One element of the update, optimizer.py:319-362 in order.
+__device__ __forceinline__ void adan_element(const AdanScalars &h, float g, float &p, float &m,
+                                             float &n, float &d, float &prev)
+{
+    const float np0 = h.first_step ? -g : prev;     // optimizer.py:187-189
+    const float diff = np0 + g;                     // :323
+    m = m * h.beta1 + h.omb1 * g;                   // :325-326
+    d = d * h.beta2 + h.omb2 * diff;                // :328-330
+    const float u = diff * h.beta2 + g;             // :332-333
+    n = n * h.beta3 + h.omb3 * (u * u);             // :334-338
+    const float denom = sqrtf(n) / h.bc3_sqrt + h.eps;  // :340-342
+    if (h.no_prox) p = p * h.decay_mul;             // :348
+    p = p + h.neg_step * (m / denom);               // :349 / :355
+    p = p + h.neg_step_diff * (d / denom);          // :350 / :356
+    if (!h.no_prox) p = p / h.decay_div;            // :360
+    prev = -g;                                      // :361-362
+}
+
+__device__ __forceinline__ void adan_inplace(const AdanScalars &h, float g, float *p, float *m,
+                                             float *n, float *d, float *prev, size_t i)
+{
+    float pi = p[i], mi = m[i], ni = n[i], di = d[i], pv = prev[i];
+    adan_element(h, g, pi, mi, ni, di, pv);
+    p[i] = pi;
+    m[i] = mi;
+    n[i] = ni;
+    d[i] = di;
+    prev[i] = pv;
+}
+
+// Tail of a fitting iteration, one lane per Gaussian: sum the Gaussian's backward partials,
+// chain them through the projection and the model's activations to the raw parameters
+// (gaussianimage_cholesky.py:62,74 / gaussianimage_rs.py:55-64), and take the Adan step on its
+// 8 (Cholesky) or 8 (RS: 2+2+1+3) parameters -- no gradient tensor is materialised.
+// Tensor slots: 0 = _xyz[N,2], 1 = _cholesky[N,3] or _scaling[N,2], 2 = _rotation[N,1] (RS),
+// 3 = _features_dc[N,3].
+template <bool RS>
+__global__ __launch_bounds__(256) void fit_tail_kernel(
+    AdanTensors T, AdanScalars h, const float *__restrict__ xys, const int *__restrict__ radii,
+    int N, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
+    const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
+    const float *__restrict__ partials, const int *__restrict__ slot_tab)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float acc[PART_STRIDE];
+    gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
+                    tile_len, seg, C, partials, slot_tab, acc);
+    const float x0 = T.p[0][2 * g], x1 = T.p[0][2 * g + 1];
+    const float t0 = tanhf(x0), t1 = tanhf(x1);
+    // means = tanh(_xyz); xys = 0.5*(W,H)*means + ...
+    const float gx0 = 0.5f * (float)W * acc[0] * (1.0f - t0 * t0);
+    const float gx1 = 0.5f * (float)H * acc[1] * (1.0f - t1 * t1);
+    float a, b, c, radius;
+    if (!RS) {
+        const float r0 = T.p[1][3 * g], r1 = T.p[1][3 * g + 1], r2 = T.p[1][3 * g + 2];
+        const float l11 = r0 + 0.5f, l21 = r1, l22 = r2 + 0.5f;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        float vm0 = 0.f, vm1 = 0.f;
+        if (cov_to_conic_radius(l11 * l11, l11 * l21, l21 * l21 + l22 * l22, a, b, c, radius)) {
+            float gxx, gxy, gyy;
+            conic_grad_to_cov_grad(a, b, c, acc[2], acc[3], acc[4], gxx, gxy, gyy);
+            o0 = 2.0f * l11 * gxx + l21 * gxy;
+            o1 = l11 * gxy + 2.0f * l21 * gyy;
+            o2 = 2.0f * l22 * gyy;
+            vm0 = gx0;
+            vm1 = gx1;
+        }
+        adan_inplace(h, vm0, T.p[0], T.m[0], T.n[0], T.d[0], T.prev[0], 2 * (size_t)g);
+        adan_inplace(h, vm1, T.p[0], T.m[0], T.n[0], T.d[0], T.prev[0], 2 * (size_t)g + 1);
+        adan_inplace(h, o0, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 3 * (size_t)g);
+        adan_inplace(h, o1, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 3 * (size_t)g + 1);
+        adan_inplace(h, o2, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 3 * (size_t)g + 2);
+    } else {
+        const float u1 = T.p[1][2 * g] + 0.5f, u2 = T.p[1][2 * g + 1] + 0.5f;
+        const float s1 = fabsf(u1), s2 = fabsf(u2);
+        const float sg = 1.0f / (1.0f + expf(-T.p[2][g]));
+        const float theta = sg * 2.0f * 3.14159274f;
+        float sn, cs;
+        sincosf(theta, &sn, &cs);
+        const float q1 = s1 * s1, q2 = s2 * s2;
+        float vs0 = 0.f, vs1 = 0.f, vr = 0.f, vm0 = 0.f, vm1 = 0.f;
+        if (cov_to_conic_radius(cs * cs * q1 + sn * sn * q2, cs * sn * (q1 - q2),
+                                sn * sn * q1 + cs * cs * q2, a, b, c, radius)) {
+            float gxx, gxy, gyy;
+            conic_grad_to_cov_grad(a, b, c, acc[2], acc[3], acc[4], gxx, gxy, gyy);
+            const float gq1 = gxx * cs * cs + gxy * cs * sn + gyy * sn * sn;
+            const float gq2 = gxx * sn * sn - gxy * cs * sn + gyy * cs * cs;
+            // d|u|/du = sign(u) (0 at 0, like torch.abs)
+            vs0 = 2.0f * s1 * gq1 * (u1 > 0.f ? 1.f : (u1 < 0.f ? -1.f : 0.f));
+            vs1 = 2.0f * s2 * gq2 * (u2 > 0.f ? 1.f : (u2 < 0.f ? -1.f : 0.f));
+            const float dq = q1 - q2;
+            const float vtheta = dq * (-2.0f * cs * sn * gxx + (cs * cs - sn * sn) * gxy +
+                                       2.0f * cs * sn * gyy);
+            vr = vtheta * 2.0f * 3.14159274f * sg * (1.0f - sg);
+            vm0 = gx0;
+            vm1 = gx1;
+        }
+        adan_inplace(h, vm0, T.p[0], T.m[0], T.n[0], T.d[0], T.prev[0], 2 * (size_t)g);
+        adan_inplace(h, vm1, T.p[0], T.m[0], T.n[0], T.d[0], T.prev[0], 2 * (size_t)g + 1);
+        adan_inplace(h, vs0, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 2 * (size_t)g);
+        adan_inplace(h, vs1, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 2 * (size_t)g + 1);
+        adan_inplace(h, vr, T.p[2], T.m[2], T.n[2], T.d[2], T.prev[2], (size_t)g);
+    }
+    adan_inplace(h, acc[5], T.p[3], T.m[3], T.n[3], T.d[3], T.prev[3], 3 * (size_t)g);
+    adan_inplace(h, acc[6], T.p[3], T.m[3], T.n[3], T.d[3], T.prev[3], 3 * (size_t)g + 1);
+    adan_inplace(h, acc[7], T.p[3], T.m[3], T.n[3], T.d[3], T.prev[3], 3 * (size_t)g + 2);
+}
+
 __global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScalars h,
                                                         const float *__restrict__ clip_dev)
 {
@@ -872,23 +1041,7 @@ __global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScala
             g = g * clip;
             gr[i] = g;  // the reference scales the gradient in place
         }
-        const float np0 = h.first_step ? -g : prev[i];   // optimizer.py:187-189
-        const float diff = np0 + g;                       // :323
-        const float mi = m[i] * h.beta1 + h.omb1 * g;     // :325-326
-        const float di = d[i] * h.beta2 + h.omb2 * diff;  // :328-330
-        const float u = diff * h.beta2 + g;               // :332-333
-        const float ni = n[i] * h.beta3 + h.omb3 * (u * u);  // :334-338
-        const float denom = sqrtf(ni) / h.bc3_sqrt + h.eps;  // :340-342
-        float pi = p[i];
-        if (h.no_prox) pi = pi * h.decay_mul;             // :348
-        pi = pi + h.neg_step * (mi / denom);              // :349 / :355
-        pi = pi + h.neg_step_diff * (di / denom);         // :350 / :356
-        if (!h.no_prox) pi = pi / h.decay_div;            // :360
-        m[i] = mi;
-        d[i] = di;
-        n[i] = ni;
-        p[i] = pi;
-        prev[i] = -g;                                     // :361-362
+        adan_inplace(h, g, p, m, n, d, prev, (size_t)i);
     }
 }
 
@@ -1172,14 +1325,17 @@ static int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hi
     return GI2D_OK;
 }
 
-int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int N, int H, int W,
-                              int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
-                              float *depths, int *radii, float *conics, int *num_tiles_hit,
-                              gi2d_workspace *ws, void *stream)
+// kind 0 = Cholesky (cov_a = L[N,3]), 1 = rotation-scale (cov_a = scales[N,2], cov_b = rotation).
+// raw = the model's raw parameters are given and activated inside the kernel.
+static int project_impl(int kind, bool raw, const float *means, const float *cov_a,
+                        const float *cov_b, int N, int H, int W, int tiles_x, int tiles_y,
+                        const gi2d_conv *conv, float *xys, float *depths, int *radii,
+                        float *conics, int *num_tiles_hit, gi2d_workspace *ws, void *stream)
 {
-    int rc = check_proj_args(means2d, L_elements, N, H, W, tiles_x, tiles_y, conv, xys, depths,
-                             radii, conics, num_tiles_hit);
+    int rc = check_proj_args(means, cov_a, N, H, W, tiles_x, tiles_y, conv, xys, depths, radii,
+                             conics, num_tiles_hit);
     if (rc != GI2D_OK) return rc;
+    if (kind == 1 && N > 0 && !cov_b) return GI2D_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     bool fill = false;
     if (ws) {
@@ -1188,13 +1344,36 @@ int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int
         fill = ws->prefilled;
     }
     if (N == 0) return GI2D_OK;
-    project_cholesky_fwd_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(
-        means2d, L_elements, N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii,
-        conics, num_tiles_hit, fill ? ws->d_count : nullptr, fill ? ws->d_seg : nullptr,
-        fill ? ws->seg_cap : 0, fill ? ws->pre_r0 : 0, fill ? ws->pre_r1 : 0,
-        fill ? ws->d_status : nullptr, fill ? ws->h_status_dev : nullptr,
-        fill ? ws->generation : 0);
+    int *cnt = fill ? ws->d_count : nullptr, *seg = fill ? ws->d_seg : nullptr;
+    const int C = fill ? ws->seg_cap : 0, r0 = fill ? ws->pre_r0 : 0, r1 = fill ? ws->pre_r1 : 0;
+    DevStatus *status = fill ? ws->d_status : nullptr;
+    long long *hs = fill ? ws->h_status_dev : nullptr;
+    const long long gen = fill ? ws->generation : 0;
+    const dim3 grid(cdiv(N, PG_THREADS)), block(PG_THREADS);
+#define GI2D_PROJ_ARGS N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii, conics, \
+                       num_tiles_hit, cnt, seg, C, r0, r1, status, hs, gen
+    if (kind == 0) {
+        if (raw)
+            project_cholesky_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, GI2D_PROJ_ARGS);
+        else
+            project_cholesky_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, GI2D_PROJ_ARGS);
+    } else {
+        if (raw)
+            project_rs_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, cov_b, GI2D_PROJ_ARGS);
+        else
+            project_rs_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, cov_b, GI2D_PROJ_ARGS);
+    }
+#undef GI2D_PROJ_ARGS
     return launch_status();
+}
+
+int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int N, int H, int W,
+                              int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
+                              float *depths, int *radii, float *conics, int *num_tiles_hit,
+                              gi2d_workspace *ws, void *stream)
+{
+    return project_impl(0, false, means2d, L_elements, nullptr, N, H, W, tiles_x, tiles_y, conv,
+                        xys, depths, radii, conics, num_tiles_hit, ws, stream);
 }
 
 int gi2d_project_rs_fwd(const float *means2d, const float *scales, const float *rotation, int N,
@@ -1202,25 +1381,8 @@ int gi2d_project_rs_fwd(const float *means2d, const float *scales, const float *
                         float *depths, int *radii, float *conics, int *num_tiles_hit,
                         gi2d_workspace *ws, void *stream)
 {
-    int rc = check_proj_args(means2d, scales, N, H, W, tiles_x, tiles_y, conv, xys, depths, radii,
-                             conics, num_tiles_hit);
-    if (rc != GI2D_OK) return rc;
-    if (N > 0 && !rotation) return GI2D_E_INVALID;
-    hipStream_t st = (hipStream_t)stream;
-    bool fill = false;
-    if (ws) {
-        rc = begin_prefill(ws, N, tiles_x, tiles_y, st);
-        if (rc != GI2D_OK) return rc;
-        fill = ws->prefilled;
-    }
-    if (N == 0) return GI2D_OK;
-    project_rs_fwd_kernel<<<cdiv(N, PG_THREADS), PG_THREADS, 0, st>>>(
-        means2d, scales, rotation, N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths,
-        radii, conics, num_tiles_hit, fill ? ws->d_count : nullptr, fill ? ws->d_seg : nullptr,
-        fill ? ws->seg_cap : 0, fill ? ws->pre_r0 : 0, fill ? ws->pre_r1 : 0,
-        fill ? ws->d_status : nullptr, fill ? ws->h_status_dev : nullptr,
-        fill ? ws->generation : 0);
-    return launch_status();
+    return project_impl(1, false, means2d, scales, rotation, N, H, W, tiles_x, tiles_y, conv, xys,
+                        depths, radii, conics, num_tiles_hit, ws, stream);
 }
 
 int gi2d_project_cholesky_bwd(const float *means2d, const float *L_elements, int N, int H, int W,
@@ -1419,10 +1581,11 @@ static int check_raster_args(gi2d_workspace *ws, int N, int H, int W, const gi2d
     return GI2D_OK;
 }
 
-int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *conics,
+// gt / v_img / loss_part non-NULL selects the fitting epilogue (then out_img may be NULL).
+static int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *conics,
                            const float *colors, const float *opacity, const float *background,
                            int N, int H, int W, const gi2d_conv *conv, float *out_img,
-                           void *stream)
+                           const float *gt, float *v_img, float *loss_part, void *stream)
 {
     int rc = check_raster_args(ws, N, H, W, conv);
     if (rc != GI2D_OK) return rc;
@@ -1433,7 +1596,10 @@ int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *co
         ws->lists_raw = false;
         return GI2D_OK;
     }
-    if (!out_img || (N > 0 && (!xys || !conics || !colors || !opacity))) return GI2D_E_INVALID;
+    const bool l2 = gt != nullptr;
+    if (l2 && (!v_img || !loss_part)) return GI2D_E_INVALID;
+    if ((!out_img && !l2) || (N > 0 && (!xys || !conics || !colors || !opacity)))
+        return GI2D_E_INVALID;
     if (conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
     float bg[3] = {0.f, 0.f, 0.f};
     if (conv->bg_weight != 0.0f) {
@@ -1441,37 +1607,39 @@ int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *co
         HIP_TRY(hipMemcpyAsync(bg, background, sizeof(bg), hipMemcpyDefault, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    if (ws->lists_raw) {
-        rasterize_sum_fwd_kernel<true><<<T, 256, 0, st>>>(
-            ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, conics, colors, opacity, bg[0],
-            bg[1], bg[2], H, W, ws->tiles_x, ws->bin_row0, T, *conv, ws->cull, ws->d_status,
-            ws->generation, out_img);
+#define GI2D_RASTER_ARGS ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, conics, colors, \
+                         opacity, bg[0], bg[1], bg[2], H, W, ws->tiles_x, ws->bin_row0, T, *conv, \
+                         ws->cull, ws->d_status, ws->generation, out_img, gt, v_img, loss_part
+    const bool fin = ws->lists_raw;
+    if (fin && l2) rasterize_sum_fwd_kernel<true, true><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+    else if (fin) rasterize_sum_fwd_kernel<true, false><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+    else if (l2) rasterize_sum_fwd_kernel<false, true><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+    else rasterize_sum_fwd_kernel<false, false><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+#undef GI2D_RASTER_ARGS
+    if (fin) {
         ws->lists_raw = false;
         ws->counters_dirty = false;
-    } else {
-        rasterize_sum_fwd_kernel<false><<<T, 256, 0, st>>>(
-            ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, conics, colors, opacity, bg[0],
-            bg[1], bg[2], H, W, ws->tiles_x, ws->bin_row0, T, *conv, ws->cull, ws->d_status,
-            ws->generation, out_img);
     }
     return launch_status();
 }
 
-int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radii,
-                           const float *conics, const float *colors, const float *opacity, int N,
-                           int H, int W, const gi2d_conv *conv, const float *v_out, float *v_xys,
-                           float *v_conics, float *v_colors, float *v_opacity, void *stream)
+int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *conics,
+                           const float *colors, const float *opacity, const float *background,
+                           int N, int H, int W, const gi2d_conv *conv, float *out_img,
+                           void *stream)
 {
-    int rc = check_raster_args(ws, N, H, W, conv);
-    if (rc != GI2D_OK) return rc;
-    if (N == 0) return GI2D_OK;
-    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
-    if (!xys || !radii || !conics || !colors || !opacity || (!v_out && T > 0) || !v_xys ||
-        !v_conics || !v_colors || !v_opacity)
-        return GI2D_E_INVALID;
-    DeviceGuard guard(ws->device);
-    hipStream_t st = (hipStream_t)stream;
-    rc = finalize_lists(ws, st);
+    return raster_fwd_impl(ws, xys, conics, colors, opacity, background, N, H, W, conv, out_img,
+                           nullptr, nullptr, nullptr, stream);
+}
+
+// Backward pass 1 (per-tile partial sums into the slab); shared by the operator backward and
+// the fused fitting step.
+static int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
+                            const float *conics, const float *colors, const float *opacity, int N,
+                            int H, int W, const gi2d_conv *conv, const float *v_out,
+                            hipStream_t st)
+{
+    int rc = finalize_lists(ws, st);
     if (rc != GI2D_OK) return rc;
     const int64_t slots = (int64_t)ws->tiles_cap * ws->seg_cap;
     if (ws->part_slots < slots) {
@@ -1491,14 +1659,33 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
         HIP_TRY(hipMemset(ws->d_slot_tab, 0, sizeof(int) * SLOT_TAB * (size_t)N));
         ws->slot_cap = N;
     }
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (T > 0) {
         rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(
             ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, colors, opacity, H, W,
             ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull, v_out,
             ws->d_partials, ws->d_slot_tab);
         rc = launch_status();
-        if (rc != GI2D_OK) return rc;
     }
+    return rc;
+}
+
+int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radii,
+                           const float *conics, const float *colors, const float *opacity, int N,
+                           int H, int W, const gi2d_conv *conv, const float *v_out, float *v_xys,
+                           float *v_conics, float *v_colors, float *v_opacity, void *stream)
+{
+    int rc = check_raster_args(ws, N, H, W, conv);
+    if (rc != GI2D_OK) return rc;
+    if (N == 0) return GI2D_OK;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (!xys || !radii || !conics || !colors || !opacity || (!v_out && T > 0) || !v_xys ||
+        !v_conics || !v_colors || !v_opacity)
+        return GI2D_E_INVALID;
+    DeviceGuard guard(ws->device);
+    hipStream_t st = (hipStream_t)stream;
+    rc = raster_bwd_pass1(ws, xys, radii, conics, colors, opacity, N, H, W, conv, v_out, st);
+    if (rc != GI2D_OK) return rc;
     gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(
         xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, ws->d_len, ws->d_seg,
         ws->seg_cap, ws->d_partials, ws->d_slot_tab, v_xys, v_conics, v_colors, v_opacity);
@@ -1554,20 +1741,13 @@ int gi2d_render_rs_fwd(gi2d_workspace *ws, const float *means2d, const float *sc
                        background, out_img, raster_begin_event, raster_end_event, stream);
 }
 
-int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
-                   float *const *exp_avg, float *const *exp_avg_sq, float *const *exp_avg_diff,
-                   float *const *neg_pre_grad, const int64_t *numel, const gi2d_adan_hyper *hyper,
-                   const float *clip_dev, void *stream)
+static int adan_scalars(const gi2d_adan_hyper *hyper, AdanScalars &h)
 {
-    if (num_tensors < 0 || !hyper || hyper->step < 1) return GI2D_E_INVALID;
-    if (num_tensors == 0) return GI2D_OK;
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !exp_avg_diff || !neg_pre_grad || !numel)
-        return GI2D_E_INVALID;
+    if (!hyper || hyper->step < 1) return GI2D_E_INVALID;
     const double b1 = hyper->beta1, b2 = hyper->beta2, b3 = hyper->beta3, lr = hyper->lr;
     const double bc1 = 1.0 - pow(b1, (double)hyper->step);
     const double bc2 = 1.0 - pow(b2, (double)hyper->step);
     const double bc3 = 1.0 - pow(b3, (double)hyper->step);
-    AdanScalars h;
     h.beta1 = (float)b1;
     h.omb1 = (float)(1.0 - b1);
     h.beta2 = (float)b2;
@@ -1582,6 +1762,89 @@ int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
     h.decay_div = (float)(1.0 + lr * hyper->weight_decay);
     h.no_prox = hyper->no_prox ? 1 : 0;
     h.first_step = hyper->step == 1 ? 1 : 0;
+    return GI2D_OK;
+}
+
+int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
+                     const float *cov_b, const float *features, const float *opacity,
+                     const float *gt_chw, int N, int H, int W, const gi2d_conv *conv, float *xys,
+                     float *depths, int *radii, float *conics, int *num_tiles_hit, float *image,
+                     float *v_image, float *loss_partials, void *stream)
+{
+    if (!ws || (kind != 0 && kind != 1) || !gt_chw) return GI2D_E_INVALID;
+    const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
+    int rc = project_impl(kind, true, xyz, cov_a, cov_b, N, H, W, tiles_x, tiles_y, conv, xys,
+                          depths, radii, conics, num_tiles_hit, ws, stream);
+    if (rc != GI2D_OK) return rc;
+    rc = gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
+    if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
+    const int late = rc;
+    rc = raster_fwd_impl(ws, xys, conics, features, opacity, nullptr, N, H, W, conv, image, gt_chw,
+                         v_image, loss_partials, stream);
+    return rc != GI2D_OK ? rc : late;
+}
+
+int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                           float *features, const float *opacity, int N, int H, int W,
+                           const gi2d_conv *conv, const float *xys, const int *radii,
+                           const float *conics, const float *v_image, float *const *exp_avg,
+                           float *const *exp_avg_sq, float *const *exp_avg_diff,
+                           float *const *neg_pre_grad, const gi2d_adan_hyper *hyper, void *stream)
+{
+    if (kind != 0 && kind != 1) return GI2D_E_INVALID;
+    int rc = check_raster_args(ws, N, H, W, conv);
+    if (rc != GI2D_OK) return rc;
+    AdanScalars h;
+    rc = adan_scalars(hyper, h);
+    if (rc != GI2D_OK) return rc;
+    if (N == 0) return GI2D_OK;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (!xyz || !cov_a || (kind == 1 && !cov_b) || !features || !opacity || !xys || !radii ||
+        !conics || (!v_image && T > 0) || !exp_avg || !exp_avg_sq || !exp_avg_diff ||
+        !neg_pre_grad)
+        return GI2D_E_INVALID;
+    AdanTensors Tn;
+    float *ps[4] = {xyz, cov_a, kind == 1 ? cov_b : xyz, features};
+    for (int k = 0; k < ADAN_MAX_TENSORS; ++k) {
+        const int src = k < 4 ? k : 0;
+        if (k < 4 && (k != 2 || kind == 1) &&
+            (!exp_avg[src] || !exp_avg_sq[src] || !exp_avg_diff[src] || !neg_pre_grad[src]))
+            return GI2D_E_INVALID;
+        Tn.p[k] = ps[src];
+        Tn.g[k] = nullptr;
+        Tn.m[k] = exp_avg[src];
+        Tn.n[k] = exp_avg_sq[src];
+        Tn.d[k] = exp_avg_diff[src];
+        Tn.prev[k] = neg_pre_grad[src];
+        Tn.numel[k] = 0;
+    }
+    DeviceGuard guard(ws->device);
+    hipStream_t st = (hipStream_t)stream;
+    rc = raster_bwd_pass1(ws, xys, radii, conics, features, opacity, N, H, W, conv, v_image, st);
+    if (rc != GI2D_OK) return rc;
+    if (kind == 0)
+        fit_tail_kernel<false><<<cdiv(N, 256), 256, 0, st>>>(
+            Tn, h, xys, radii, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1,
+            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_slot_tab);
+    else
+        fit_tail_kernel<true><<<cdiv(N, 256), 256, 0, st>>>(
+            Tn, h, xys, radii, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1,
+            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_slot_tab);
+    return launch_status();
+}
+
+int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
+                   float *const *exp_avg, float *const *exp_avg_sq, float *const *exp_avg_diff,
+                   float *const *neg_pre_grad, const int64_t *numel, const gi2d_adan_hyper *hyper,
+                   const float *clip_dev, void *stream)
+{
+    if (num_tensors < 0) return GI2D_E_INVALID;
+    AdanScalars h;
+    int rcs = adan_scalars(hyper, h);
+    if (rcs != GI2D_OK) return rcs;
+    if (num_tensors == 0) return GI2D_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !exp_avg_diff || !neg_pre_grad || !numel)
+        return GI2D_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < num_tensors; base += ADAN_MAX_TENSORS) {
         AdanTensors T;

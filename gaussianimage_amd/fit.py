@@ -1,0 +1,128 @@
+"""Fused fitting loop: the reference's ``train_iter`` (forward, L2 loss, backward, Adan step --
+/root/reference/gaussianimage_cholesky.py:101-124, /root/reference/gaussianimage_rs.py:82-95)
+in four launches on the model's raw parameters, with no gradient tensors and no host
+synchronisation (``gi2d_fit_forward`` + ``gi2d_fit_backward_step``).
+
+This is an optional fast path beside the drop-in operators (which the reference's own model
+files keep using unchanged).  Parameter names and shapes are the reference model's
+(``_xyz``, ``_cholesky`` / ``_scaling`` + ``_rotation``, ``_features_dc``, buffer ``_opacity``),
+so a ``state_dict`` moves between the two.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import BLOCK, check, lib
+from .ops import Workspace, _ptr, _stream, get_conventions
+
+__all__ = ["FusedFitter"]
+
+
+class FusedFitter:
+    def __init__(self, num_points, H, W, kind="cholesky", device="cuda:0", lr=1e-3,
+                 betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0, no_prox=False,
+                 lr_step=20000, lr_gamma=0.5, params=None, keep_image=True):
+        if kind not in ("cholesky", "rs"):
+            raise ValueError("kind must be 'cholesky' or 'rs'")
+        self.kind, self.N, self.H, self.W = kind, int(num_points), int(H), int(W)
+        self.device = torch.device(device)
+        self.lr0, self.betas, self.eps = lr, betas, eps
+        self.weight_decay, self.no_prox = weight_decay, no_prox
+        self.lr_step, self.lr_gamma = lr_step, lr_gamma
+        N, d, f32 = self.N, self.device, torch.float32
+        if params is None:  # the reference's initial distributions
+            params = {"_xyz": torch.atanh(2 * (torch.rand(N, 2) - 0.5)),
+                      "_features_dc": torch.rand(N, 3)}
+            if kind == "cholesky":
+                params["_cholesky"] = torch.rand(N, 3)
+            else:
+                params["_scaling"] = torch.rand(N, 2)
+                params["_rotation"] = torch.rand(N, 1)
+        names = (["_xyz", "_cholesky", None, "_features_dc"] if kind == "cholesky" else
+                 ["_xyz", "_scaling", "_rotation", "_features_dc"])
+        self.names = names
+        self.params = {k: params[k].detach().to(d, f32).contiguous().clone()
+                       for k in names if k}
+        self._opacity = torch.ones(N, 1, dtype=f32, device=d)
+        self.state = {k: {s: torch.zeros_like(p) for s in
+                          ("exp_avg", "exp_avg_sq", "exp_avg_diff", "neg_pre_grad")}
+                      for k, p in self.params.items()}
+        self.step_count = 0
+        self.ws = Workspace(d)
+        self.conv = _lib.default_conv(**get_conventions())
+        self.tiles = ((W + BLOCK - 1) // BLOCK) * ((H + BLOCK - 1) // BLOCK)
+        i32 = torch.int32
+        self.xys = torch.empty(N, 2, dtype=f32, device=d)
+        self.depths = torch.empty(N, dtype=f32, device=d)
+        self.radii = torch.empty(N, dtype=i32, device=d)
+        self.conics = torch.empty(N, 3, dtype=f32, device=d)
+        self.num_tiles_hit = torch.empty(N, dtype=i32, device=d)
+        self.image = torch.empty(H, W, 3, dtype=f32, device=d) if keep_image else None
+        self.v_image = torch.empty(H, W, 3, dtype=f32, device=d)
+        self.loss_partials = torch.zeros(self.tiles, dtype=f32, device=d)
+        self._bind()
+
+    def _bind(self):
+        p = [self.params[k] if k else None for k in self.names]
+        self._kind = 0 if self.kind == "cholesky" else 1
+        self._fwd_args = (self.ws.handle, self._kind, _ptr(p[0]), _ptr(p[1]), _ptr(p[2]),
+                          _ptr(p[3]), _ptr(self._opacity))
+        self._fwd_tail = (self.N, self.H, self.W, ctypes.byref(self.conv), _ptr(self.xys),
+                          _ptr(self.depths), _ptr(self.radii), _ptr(self.conics),
+                          _ptr(self.num_tiles_hit), _ptr(self.image), _ptr(self.v_image),
+                          _ptr(self.loss_partials))
+        arr = lambda key: (ctypes.c_void_p * 4)(*[  # noqa: E731
+            self.state[k][key].data_ptr() if k else None for k in self.names])
+        self._state_arrays = tuple(arr(k) for k in
+                                   ("exp_avg", "exp_avg_sq", "exp_avg_diff", "neg_pre_grad"))
+        self._bwd_args = (self.ws.handle, self._kind, _ptr(p[0]), _ptr(p[1]), _ptr(p[2]),
+                          _ptr(p[3]), _ptr(self._opacity), self.N, self.H, self.W,
+                          ctypes.byref(self.conv), _ptr(self.xys), _ptr(self.radii),
+                          _ptr(self.conics), _ptr(self.v_image), *self._state_arrays)
+        self._stream = _stream(self.device)
+
+    @property
+    def lr(self):
+        """StepLR(step_size, gamma) of the reference (gaussianimage_cholesky.py:55,123)."""
+        return self.lr0 * self.lr_gamma ** (self.step_count // self.lr_step)
+
+    def forward(self, gt_image):
+        """Renders and evaluates the loss gradient; ``gt_image``: [1,3,H,W] or [3,H,W] float32."""
+        if gt_image.device != self.device or gt_image.dtype != torch.float32 or \
+                not gt_image.is_contiguous() or gt_image.numel() != 3 * self.H * self.W:
+            raise ValueError("gt_image must be a contiguous float32 [1,3,H,W] tensor on the device")
+        rc = lib.gi2d_fit_forward(*self._fwd_args, _ptr(gt_image), *self._fwd_tail, self._stream)
+        check(rc, "gi2d_fit_forward")
+
+    def step(self, gt_image):
+        """One fitting iteration (forward, loss, backward, Adan).  Returns nothing: read
+        ``loss()`` / ``psnr()`` when needed -- they synchronise, the step does not."""
+        lr = self.lr
+        self.forward(gt_image)
+        self.step_count += 1
+        b1, b2, b3 = self.betas
+        hyper = _lib.AdanHyper(lr, b1, b2, b3, self.eps, self.weight_decay,
+                               int(bool(self.no_prox)), self.step_count)
+        rc = lib.gi2d_fit_backward_step(*self._bwd_args, ctypes.byref(hyper), self._stream)
+        check(rc, "gi2d_fit_backward_step")
+
+    def loss(self):
+        """Mean squared error of the last forward (before that step's update)."""
+        return float(self.loss_partials.double().sum().item()) / (3 * self.H * self.W)
+
+    def psnr(self):
+        return 10 * math.log10(1.0 / max(self.loss(), 1e-30))
+
+    def render(self):
+        """The last forward's image as the model returns it: [1,3,H,W], clamped to [0,1]."""
+        if self.image is None:
+            raise RuntimeError("created with keep_image=False")
+        return torch.clamp(self.image, 0, 1).view(-1, self.H, self.W, 3).permute(
+            0, 3, 1, 2).contiguous()
+
+    def state_dict(self):
+        sd = {k: v.clone() for k, v in self.params.items()}
+        sd["_opacity"] = self._opacity.clone()
+        return sd

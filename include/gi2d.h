@@ -170,6 +170,34 @@ int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
                    float *const *neg_pre_grad, const int64_t *numel, const gi2d_adan_hyper *hyper,
                    const float *clip_dev, void *stream);
 
+/* Fused fitting iteration on the model's RAW parameters -- the caller's loop of
+ * gaussianimage_cholesky.py:101-124 / gaussianimage_rs.py:82-95 (forward, L2
+ * loss, backward, Adan step) in FOUR launches and no gradient tensors.
+ * kind 0: _xyz[N,2], cov_a = _cholesky[N,3], cov_b unused, features[N,3];
+ * kind 1: cov_a = _scaling[N,2], cov_b = _rotation[N,1].  The activations
+ * (tanh, +cholesky_bound / |.+0.5|, sigmoid*2pi) are applied inside.
+ *
+ * gi2d_fit_forward: projection + binning + rasterisation with the loss
+ * epilogue: v_image[H,W,3] = d mse(clamp(img,0,1), gt) / d img, with gt stored
+ * [3,H,W] like the model's gt_image; loss_partials[tiles] = per-tile sums of
+ * squared errors (mse = sum / (3*H*W)); image[H,W,3] optional (NULL to skip).
+ * gi2d_fit_backward_step: backward rasterisation, then per Gaussian the sum of
+ * its partials, the chain through projection and activations, and the Adan
+ * update of its parameters in place.  State arrays hold 4 device pointers
+ * each, in the order (_xyz, cov_a, cov_b, features); slot 2 is ignored for
+ * kind 0. */
+int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
+                     const float *cov_b, const float *features, const float *opacity,
+                     const float *gt_chw, int N, int H, int W, const gi2d_conv *conv, float *xys,
+                     float *depths, int *radii, float *conics, int *num_tiles_hit, float *image,
+                     float *v_image, float *loss_partials, void *stream);
+int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                           float *features, const float *opacity, int N, int H, int W,
+                           const gi2d_conv *conv, const float *xys, const int *radii,
+                           const float *conics, const float *v_image, float *const *exp_avg,
+                           float *const *exp_avg_sq, float *const *exp_avg_diff,
+                           float *const *neg_pre_grad, const gi2d_adan_hyper *hyper, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

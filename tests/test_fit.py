@@ -1,0 +1,82 @@
+"""The fused fitting step against the drop-in path: same parameters after K iterations as the
+reference-style loop (drop-in operators + torch autograd + the reference-pinned Adan), and the
+loss / image of its forward against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gaussianimage_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _maxrel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("kind", ["cholesky", "rs"])
+def test_fused_step_matches_drop_in_training(kind):
+    from gaussianimage_amd import harness
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N, K = 96, 128, 1500, 6
+    torch.manual_seed(3)
+    if kind == "cholesky":
+        model = harness.CholeskyImageModel(N, H, W, DEV, lr=5e-3, passes=1)
+        names = ["_xyz", "_cholesky", "_features_dc"]
+    else:
+        model = harness.RSImageModel(N, H, W, DEV, lr=5e-3)
+        names = ["_xyz", "_scaling", "_rotation", "_features_dc"]
+    params = {k: getattr(model, k).detach().clone() for k in names}
+    fit = FusedFitter(N, H, W, kind=kind, device=DEV, lr=5e-3, params=params)
+    gt = synth.target_image(H, W).to(DEV)
+    for it in range(K):
+        loss, _ = model.train_iter(gt)
+        fit.step(gt)
+        assert abs(fit.loss() - loss.item()) <= 2e-6 * max(1.0, loss.item())
+    for k in names:
+        # fp32 trajectories of two implementations: equal to a few 1e-5 of the parameter range
+        assert _maxrel(fit.params[k], getattr(model, k)) <= 2e-4, k
+    img = model.forward()["render"]
+    fit.forward(gt)
+    assert float((fit.render() - img.detach()).abs().max()) <= 1e-4
+
+
+def test_fit_forward_loss_and_gradient_against_oracle(oracle):
+    """gi2d_fit_forward alone: image, per-tile loss sums and d mse / d image vs the oracle."""
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N = 80, 112, 800
+    xyz, chol, feat = synth.cholesky_params(N, seed=5, footprint=2.0)
+    fit = FusedFitter(N, H, W, device=DEV, params={"_xyz": xyz, "_cholesky": chol,
+                                                   "_features_dc": feat})
+    gt = synth.target_image(H, W).to(DEV)
+    fit.forward(gt)
+    means, L, col, op = synth.cholesky_inputs(N, seed=5, footprint=2.0)
+    ref, margin = None, None
+    xys, _, radii, conics, _ = oracle.project_cholesky_fwd(means.numpy(), L.numpy(), H, W)
+    offs, ids = oracle.bin_tiles(xys, radii, H, W)
+    ref, margin = oracle.rasterize_sum_fwd(xys, conics, col.numpy(), op.numpy(), H, W, offs, ids,
+                                           want_margin=True)
+    ok = margin > 1e-3
+    assert np.abs(fit.image.cpu().numpy() - ref)[ok].max() <= 2e-5
+    g = gt[0].permute(1, 2, 0).cpu().numpy()
+    d = np.clip(ref, 0, 1) - g
+    assert abs(fit.loss() - float((d.astype(np.float64) ** 2).mean())) <= 1e-6
+    v = 2 * d / d.size * ((ref >= 0) & (ref <= 1))
+    assert np.abs(fit.v_image.cpu().numpy() - v)[ok].max() <= 1e-9 + 1e-4 * np.abs(v).max()
+
+
+def test_fused_fit_reduces_the_loss():
+    """End to end: PSNR rises over a short fit of a synthetic image."""
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N = 128, 192, 4000
+    torch.manual_seed(0)
+    fit = FusedFitter(N, H, W, device=DEV, lr=1e-2)
+    gt = synth.target_image(H, W).to(DEV)
+    fit.step(gt)
+    first = fit.psnr()
+    for _ in range(300):
+        fit.step(gt)
+    last = fit.psnr()
+    assert last > first + 6.0, (first, last)
