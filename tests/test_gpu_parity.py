@@ -396,3 +396,53 @@ def test_tile_row_bands_equal_the_unsharded_frame(ops, oracle, kind):
             sums = grads if sums is None else [s + g for s, g in zip(sums, grads)]
         for s, r in zip(sums, ref_grads):
             assert _maxrel(_np(s), _np(r)) <= 1e-5
+
+
+def test_asynchronous_overflow_is_loud_and_repaired(ops, oracle):
+    """A steady-state (no host synchronisation) frame whose tile lists outgrow the capacity
+    sized from earlier frames: the overflowed tiles come out NaN (never silently wrong), a later
+    binning call reports it once, and after that the same frame renders correctly."""
+    from gaussianimage_amd import _lib
+    H, W, N = 64, 64, 4000
+    g = torch.Generator().manual_seed(21)
+    xys = (torch.rand(N, 2, generator=g) * torch.tensor([W, H])).to(DEV)
+    small = torch.ones(N, dtype=torch.int32, device=DEV)          # ~1-2 tiles per Gaussian
+    big = torch.full((N,), 40, dtype=torch.int32, device=DEV)      # every tile
+    conics = torch.tensor([[0.02, 0.0, 0.02]]).repeat(N, 1).to(DEV)
+    col = torch.rand(N, 3, generator=g).to(DEV)
+    opa = torch.ones(N, 1, device=DEV)
+    z = torch.zeros(N, device=DEV)
+    nth = torch.zeros(N, dtype=torch.int32, device=DEV)
+    # a fresh workspace: the shared one has grown in earlier tests and never shrinks
+    idx = torch.device(DEV).index or 0
+    saved = ops._WORKSPACES.get(idx)
+    ops._WORKSPACES[idx] = ops.Workspace(DEV)
+    try:
+        _overflow_scenario(ops, oracle, xys, small, big, conics, col, opa, z, nth, H, W)
+    finally:
+        ops._WORKSPACES[idx] = saved
+
+
+def _overflow_scenario(ops, oracle, xys, small, big, conics, col, opa, z, nth, H, W):
+    from gaussianimage_amd import _lib
+
+    def render(radii):
+        return ops.rasterize_gaussians_sum(xys, z, radii, conics, nth, col, opa, H, W, 16, 16)
+
+    render(small)                       # learns the shape synchronously, capacity ~2x its lists
+    img = render(big.clone())           # same shape, asynchronous: lists 10x longer
+    assert torch.isnan(img).any(), "overflowed tiles must be NaN"
+    reported = 0
+    ok_img = None
+    for _ in range(5):                  # each overflowed frame is reported once, by a later call
+        try:
+            ok_img = render(big.clone())
+        except _lib.Gi2dError as e:
+            assert e.status == _lib.GI2D_E_PREV_OVERFLOW
+            reported += 1
+    assert 1 <= reported <= 2           # the frame above, and the one issued before the report
+    ok_img = render(big.clone())
+    offs, ids = oracle.bin_tiles(_np(xys), _np(big), H, W)
+    ref = oracle.rasterize_sum_fwd(_np(xys), _np(conics), _np(col), _np(opa), H, W, offs, ids)
+    assert not torch.isnan(ok_img).any()
+    assert np.abs(_np(ok_img) - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
