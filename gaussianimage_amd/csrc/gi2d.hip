@@ -493,14 +493,19 @@ __device__ __forceinline__ void support_rect(float gx, float gy, float a, float 
                                              float op, float alpha_min, float ox, float oy,
                                              int &x0, int &x1, int &y0, int &y1)
 {
+    // hardware-approximate rcp / log / sqrt (1 ulp) are enough here: the bound is padded by
+    // 0.1 % + 1e-3 px twice over, and the exact alpha test still decides every pixel inside it
     const float det = a * c - b * b;
-    const float ratio = op / alpha_min;
-    if (!(ratio >= 1.0f)) {
-        x1 = x0 - 1;  // opacity below the cut: no pixel can reach alpha_min
+    const float ratio = op * __builtin_amdgcn_rcpf(alpha_min);
+    if (!(ratio >= 1.0005f)) {
+        // opacity at or below the cut (within the rcp's rounding): leave the decision to the
+        // exact per-pixel test unless it is clearly below
+        if (!(ratio >= 0.9995f)) x1 = x0 - 1;  // no pixel can reach alpha_min
     } else if (a > 0.f && c > 0.f && det > 1.0e-3f * a * c && ratio < 3.0e38f) {
         const float tau = 1.001f * __logf(ratio) + 1.0e-3f;
-        const float hx = 1.001f * sqrtf(2.0f * tau * c / det) + 1.0e-3f;
-        const float hy = 1.001f * sqrtf(2.0f * tau * a / det) + 1.0e-3f;
+        const float k2 = 2.0f * tau * __builtin_amdgcn_rcpf(det);
+        const float hx = 1.001f * __builtin_amdgcn_sqrtf(k2 * c) + 1.0e-3f;
+        const float hy = 1.001f * __builtin_amdgcn_sqrtf(k2 * a) + 1.0e-3f;
         if (hx < 1.0e6f && hy < 1.0e6f) {
             axis_range(gx, ox, hx, x0, x1, x0, x1);
             axis_range(gy, oy, hy, y0, y1, y0, y1);
@@ -705,9 +710,11 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     __shared__ float4 s_v[256];
     const int tid = threadIdx.x;
     const int t = xcd_tile(blockIdx.x, T);
+    const int *lst = seg + (size_t)t * C;
+    // first batch's id before the length is known (a segment always has C >= 64 words)
+    const int gid_first = lst[tid >> 2];
     const int n_raw = tile_len[t];
     if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
-    const int *lst = seg + (size_t)t * C;
     const size_t slot0 = (size_t)t * C;
     const int tx = t % tiles_x, ty = row0 + t / tiles_x;
     {
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
         int gid = 0, rad = 0;
         float gx = 0.f, gy = 0.f;
         if (e < n_raw) {
-            gid = lst[e];
+            gid = base == 0 ? gid_first : lst[e];
             gx = xys[2 * gid];
             gy = xys[2 * gid + 1];
             rad = radii[gid];
@@ -747,7 +754,9 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
             const int w = x1 - x0 + 1, h = y1 - y0 + 1;
             const int cnt = (w > 0 && h > 0) ? w * h : 0;
             // the four lanes of the quad take the rectangle's pixels round-robin
-            const int step_y = cnt ? 4 / w : 0, step_x = cnt ? 4 - step_y * w : 0;
+            // 4 / w for w in 1..16 without the integer-division sequence
+            const int step_y = cnt ? (w > 4 ? 0 : (w > 2 ? 1 : (w == 2 ? 2 : 4))) : 0;
+            const int step_x = cnt ? 4 - step_y * w : 0;
             int x = x0 + q, y = y0;
             while (cnt && x > x1) {
                 x -= w;
