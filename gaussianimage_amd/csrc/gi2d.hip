@@ -958,6 +958,33 @@ __device__ __forceinline__ void adan_inplace(const AdanScalars &h, float g, floa
 // 8 (Cholesky) or 8 (RS: 2+2+1+3) parameters -- no gradient tensor is materialised.
 // Tensor slots: 0 = _xyz[N,2], 1 = _cholesky[N,3] or _scaling[N,2], 2 = _rotation[N,1] (RS),
 // 3 = _features_dc[N,3].
+// One parameter element with its optimizer state, held in registers.
+struct AdanSlot {
+    float p, m, n, d, prev;
+};
+
+__device__ __forceinline__ AdanSlot adan_load(const AdanTensors &T, int k, size_t i)
+{
+    AdanSlot s;
+    s.p = T.p[k][i];
+    s.m = T.m[k][i];
+    s.n = T.n[k][i];
+    s.d = T.d[k][i];
+    s.prev = T.prev[k][i];
+    return s;
+}
+
+__device__ __forceinline__ void adan_apply(const AdanScalars &h, const AdanTensors &T, int k,
+                                           size_t i, AdanSlot s, float g)
+{
+    adan_element(h, g, s.p, s.m, s.n, s.d, s.prev);
+    T.p[k][i] = s.p;
+    T.m[k][i] = s.m;
+    T.n[k][i] = s.n;
+    T.d[k][i] = s.d;
+    T.prev[k][i] = s.prev;
+}
+
 template <bool RS>
 __global__ __launch_bounds__(256) void fit_tail_kernel(
     AdanTensors T, AdanScalars h, const float *__restrict__ xys, const int *__restrict__ radii,
@@ -967,20 +994,25 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
+    // Parameters and optimizer state first: these loads do not depend on the gather below, so
+    // they are in flight while its three dependent rounds (table, lengths, partials) complete.
+    const size_t g2 = 2 * (size_t)g, g3 = 3 * (size_t)g;
+    const AdanSlot x0 = adan_load(T, 0, g2), x1 = adan_load(T, 0, g2 + 1);
+    const AdanSlot c0 = adan_load(T, 1, RS ? g2 : g3), c1 = adan_load(T, 1, (RS ? g2 : g3) + 1);
+    const AdanSlot c2 = adan_load(T, RS ? 2 : 1, RS ? (size_t)g : g3 + 2);
+    const AdanSlot f0 = adan_load(T, 3, g3), f1 = adan_load(T, 3, g3 + 1),
+                   f2 = adan_load(T, 3, g3 + 2);
     float acc[PART_STRIDE];
     gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
                     tile_len, seg, C, partials, slot_tab, acc);
-    const float x0 = T.p[0][2 * g], x1 = T.p[0][2 * g + 1];
-    const float t0 = tanhf(x0), t1 = tanhf(x1);
+    const float t0 = tanhf(x0.p), t1 = tanhf(x1.p);
     // means = tanh(_xyz); xys = 0.5*(W,H)*means + ...
     const float gx0 = 0.5f * (float)W * acc[0] * (1.0f - t0 * t0);
     const float gx1 = 0.5f * (float)H * acc[1] * (1.0f - t1 * t1);
     float a, b, c, radius;
+    float vm0 = 0.f, vm1 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
     if (!RS) {
-        const float r0 = T.p[1][3 * g], r1 = T.p[1][3 * g + 1], r2 = T.p[1][3 * g + 2];
-        const float l11 = r0 + 0.5f, l21 = r1, l22 = r2 + 0.5f;
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-        float vm0 = 0.f, vm1 = 0.f;
+        const float l11 = c0.p + 0.5f, l21 = c1.p, l22 = c2.p + 0.5f;
         if (cov_to_conic_radius(l11 * l11, l11 * l21, l21 * l21 + l22 * l22, a, b, c, radius)) {
             float gxx, gxy, gyy;
             conic_grad_to_cov_grad(a, b, c, acc[2], acc[3], acc[4], gxx, gxy, gyy);
@@ -990,20 +1022,14 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
             vm0 = gx0;
             vm1 = gx1;
         }
-        adan_inplace(h, vm0, T.p[0], T.m[0], T.n[0], T.d[0], T.prev[0], 2 * (size_t)g);
-        adan_inplace(h, vm1, T.p[0], T.m[0], T.n[0], T.d[0], T.prev[0], 2 * (size_t)g + 1);
-        adan_inplace(h, o0, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 3 * (size_t)g);
-        adan_inplace(h, o1, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 3 * (size_t)g + 1);
-        adan_inplace(h, o2, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 3 * (size_t)g + 2);
     } else {
-        const float u1 = T.p[1][2 * g] + 0.5f, u2 = T.p[1][2 * g + 1] + 0.5f;
+        const float u1 = c0.p + 0.5f, u2 = c1.p + 0.5f;
         const float s1 = fabsf(u1), s2 = fabsf(u2);
-        const float sg = 1.0f / (1.0f + expf(-T.p[2][g]));
+        const float sg = 1.0f / (1.0f + expf(-c2.p));
         const float theta = sg * 2.0f * 3.14159274f;
         float sn, cs;
         sincosf(theta, &sn, &cs);
         const float q1 = s1 * s1, q2 = s2 * s2;
-        float vs0 = 0.f, vs1 = 0.f, vr = 0.f, vm0 = 0.f, vm1 = 0.f;
         if (cov_to_conic_radius(cs * cs * q1 + sn * sn * q2, cs * sn * (q1 - q2),
                                 sn * sn * q1 + cs * cs * q2, a, b, c, radius)) {
             float gxx, gxy, gyy;
@@ -1011,24 +1037,24 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
             const float gq1 = gxx * cs * cs + gxy * cs * sn + gyy * sn * sn;
             const float gq2 = gxx * sn * sn - gxy * cs * sn + gyy * cs * cs;
             // d|u|/du = sign(u) (0 at 0, like torch.abs)
-            vs0 = 2.0f * s1 * gq1 * (u1 > 0.f ? 1.f : (u1 < 0.f ? -1.f : 0.f));
-            vs1 = 2.0f * s2 * gq2 * (u2 > 0.f ? 1.f : (u2 < 0.f ? -1.f : 0.f));
+            o0 = 2.0f * s1 * gq1 * (u1 > 0.f ? 1.f : (u1 < 0.f ? -1.f : 0.f));
+            o1 = 2.0f * s2 * gq2 * (u2 > 0.f ? 1.f : (u2 < 0.f ? -1.f : 0.f));
             const float dq = q1 - q2;
             const float vtheta = dq * (-2.0f * cs * sn * gxx + (cs * cs - sn * sn) * gxy +
                                        2.0f * cs * sn * gyy);
-            vr = vtheta * 2.0f * 3.14159274f * sg * (1.0f - sg);
+            o2 = vtheta * 2.0f * 3.14159274f * sg * (1.0f - sg);
             vm0 = gx0;
             vm1 = gx1;
         }
-        adan_inplace(h, vm0, T.p[0], T.m[0], T.n[0], T.d[0], T.prev[0], 2 * (size_t)g);
-        adan_inplace(h, vm1, T.p[0], T.m[0], T.n[0], T.d[0], T.prev[0], 2 * (size_t)g + 1);
-        adan_inplace(h, vs0, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 2 * (size_t)g);
-        adan_inplace(h, vs1, T.p[1], T.m[1], T.n[1], T.d[1], T.prev[1], 2 * (size_t)g + 1);
-        adan_inplace(h, vr, T.p[2], T.m[2], T.n[2], T.d[2], T.prev[2], (size_t)g);
     }
-    adan_inplace(h, acc[5], T.p[3], T.m[3], T.n[3], T.d[3], T.prev[3], 3 * (size_t)g);
-    adan_inplace(h, acc[6], T.p[3], T.m[3], T.n[3], T.d[3], T.prev[3], 3 * (size_t)g + 1);
-    adan_inplace(h, acc[7], T.p[3], T.m[3], T.n[3], T.d[3], T.prev[3], 3 * (size_t)g + 2);
+    adan_apply(h, T, 0, g2, x0, vm0);
+    adan_apply(h, T, 0, g2 + 1, x1, vm1);
+    adan_apply(h, T, 1, RS ? g2 : g3, c0, o0);
+    adan_apply(h, T, 1, (RS ? g2 : g3) + 1, c1, o1);
+    adan_apply(h, T, RS ? 2 : 1, RS ? (size_t)g : g3 + 2, c2, o2);
+    adan_apply(h, T, 3, g3, f0, acc[5]);
+    adan_apply(h, T, 3, g3 + 1, f1, acc[6]);
+    adan_apply(h, T, 3, g3 + 2, f2, acc[7]);
 }
 
 __global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScalars h,
