@@ -134,12 +134,16 @@ class ShardedFrame:
         self.render_band(means, cov_a, cov_b, colors, opacity)
         return self.gather.gather(async_op=async_op)
 
+    def band_grad(self, v_image):
+        """This rank's rows of a full ``[H,W,3]`` image gradient (a contiguous view)."""
+        y0, y1 = band_pixels(self.gather.plan, self.rank, self.H)
+        return v_image[y0:y1]
+
     def backward(self, means, cov_a, cov_b, colors, opacity, v_image):
         """``v_image`` is the full ``[H,W,3]`` image gradient (every rank has it, or at least
         its own band of it); returns the summed parameter gradients on every rank."""
-        y0, y1 = band_pixels(self.gather.plan, self.rank, self.H)
-        v_band = v_image[y0:y1].contiguous()
-        grads = self.pipe.backward(means, cov_a, cov_b, colors, opacity, v_band)
+        grads = self.pipe.backward(means, cov_a, cov_b, colors, opacity,
+                                   self.band_grad(v_image))
         all_reduce_grads(list(grads), self.group)
         return grads
 
@@ -187,10 +191,18 @@ def bench_tile_row_sharded(device, rank, world, steps=50, warmup=5, workload="uh
         if w is not None:
             w.wait()
     torch.cuda.synchronize()
+    # training direction: band forward + band backward, then ONE all-reduce of the flat
+    # parameter-gradient buffer (8 floats per Gaussian)
+    v_image = torch.randn(H, W, 3, device=device)
+    t_fb = timed(lambda: (frame.render_band(*inputs),
+                          frame.pipe.backward(*inputs, frame.band_grad(v_image))))
+    t_fb_ar = timed(lambda: (frame.render_band(*inputs), frame.backward(*inputs, v_image)))
     return {"workload": f"{workload}: {W}x{H}, {N} Gaussians, tile rows split over {world} ranks",
             "band_rows": frame.gather.plan, "compute_only_ms": t_compute * 1e3,
             "compute_plus_allgather_ms": t_total * 1e3,
             "overlapped_allgather_ms": t_overlap * 1e3,
             "fps_compute_only": 1.0 / t_compute, "fps_with_allgather": 1.0 / t_total,
             "fps_overlapped": 1.0 / t_overlap, "scaling": "strong",
-            "allgather_bytes_per_rank": frame.gather.slot_rows * W * 3 * 4}
+            "allgather_bytes_per_rank": frame.gather.slot_rows * W * 3 * 4,
+            "fwd_bwd_compute_only_ms": t_fb * 1e3, "fwd_bwd_plus_allreduce_ms": t_fb_ar * 1e3,
+            "allreduce_bytes": 8 * N * 4}
