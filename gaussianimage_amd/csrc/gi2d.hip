@@ -1105,6 +1105,7 @@ struct gi2d_workspace {
     int bin_row0 = 0, bin_row1 = 0;  // tile rows of the current lists
     bool counters_dirty = false;     // counters may be non-zero
     bool lists_raw = false;          // lists filled but not yet sorted / finalised
+    bool lists_valid = false;        // lists belong to the binning that (tiles_x, ...) describe
     bool prefilled = false;          // project_*_fwd filled the lists for the shape below
     int pre_n = 0, pre_tx = 0, pre_ty = 0, pre_r0 = 0, pre_r1 = 0;
     int cull = 1;
@@ -1132,6 +1133,7 @@ struct DeviceGuard {
     bool ok = true;
     explicit DeviceGuard(int dev)
     {
+        if (dev < 0) return;  // nothing to guard
         if (hipGetDevice(&prev) != hipSuccess) ok = false;
         if (ok && prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
     }
@@ -1169,6 +1171,7 @@ static int ensure_lists(gi2d_workspace *ws, int T, int C)
     ws->seg_cap = C;
     ws->counters_dirty = false;
     ws->lists_raw = false;
+    ws->lists_valid = false;
     ws->prefilled = false;
     ws->tiles_x = ws->tiles_y = 0;  // no valid lists
     return GI2D_OK;
@@ -1350,7 +1353,8 @@ static int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hi
         if (rc != GI2D_OK) return rc;
     }
     ws->counters_dirty = true;
-    ws->lists_raw = false;  // the old lists are about to be overwritten
+    ws->lists_raw = false;
+    ws->lists_valid = false;  // the old lists are about to be overwritten
     ws->prefilled = true;
     ws->pre_n = N;
     ws->pre_tx = tiles_x;
@@ -1373,7 +1377,9 @@ static int project_impl(int kind, bool raw, const float *means, const float *cov
     if (kind == 1 && N > 0 && !cov_b) return GI2D_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     bool fill = false;
+    DeviceGuard guard(ws ? ws->device : -1);
     if (ws) {
+        if (!guard.ok) return GI2D_E_INVALID;
         rc = begin_prefill(ws, N, tiles_x, tiles_y, st);
         if (rc != GI2D_OK) return rc;
         fill = ws->prefilled;
@@ -1507,11 +1513,13 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     ws->n_binned = N;
     ws->bin_row0 = r0;
     ws->bin_row1 = r1;
+    ws->lists_valid = false;
     if (!prefilled) {
         int rc = launch_bin(ws, xys, radii, N, tiles_x, tiles_y, r0, r1, st);
         if (rc != GI2D_OK) return rc;
     }
     ws->lists_raw = true;
+    ws->lists_valid = true;
 
     if (sync) {
         // finalise now, read the list lengths, and redo the binning if a segment overflowed
@@ -1553,6 +1561,7 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
             rc = launch_bin(ws, xys, radii, N, tiles_x, tiles_y, r0, r1, st);
             if (rc != GI2D_OK) return rc;
             ws->lists_raw = true;
+            ws->lists_valid = true;
         }
     }
     return prev_overflow ? GI2D_E_PREV_OVERFLOW : GI2D_OK;
@@ -1562,7 +1571,7 @@ int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_
                    void *stream)
 {
     if (!ws || !tile_offsets) return GI2D_E_INVALID;
-    if (ws->generation == 0 || ws->tiles_x == 0) return GI2D_E_STATE;
+    if (ws->generation == 0 || ws->tiles_x == 0 || !ws->lists_valid) return GI2D_E_STATE;
     DeviceGuard guard(ws->device);
     hipStream_t st = (hipStream_t)stream;
     int rc = finalize_lists(ws, st);
@@ -1609,7 +1618,7 @@ int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_
 static int check_raster_args(gi2d_workspace *ws, int N, int H, int W, const gi2d_conv *conv)
 {
     if (!ws || !conv || N < 0 || H < 1 || W < 1) return GI2D_E_INVALID;
-    if (ws->generation == 0 || ws->tiles_x == 0) return GI2D_E_STATE;
+    if (ws->generation == 0 || ws->tiles_x == 0 || !ws->lists_valid) return GI2D_E_STATE;
     if (ws->tiles_x != cdiv(W, GI2D_BLOCK) || ws->tiles_y != cdiv(H, GI2D_BLOCK) ||
         ws->n_binned != N)
         return GI2D_E_STATE;

@@ -446,3 +446,44 @@ def _overflow_scenario(ops, oracle, xys, small, big, conics, col, opa, z, nth, H
     ref = oracle.rasterize_sum_fwd(_np(xys), _np(conics), _np(col), _np(opa), H, W, offs, ids)
     assert not torch.isnan(ok_img).any()
     assert np.abs(_np(ok_img) - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_frame_pipeline_equals_operator_path_and_state_errors(ops, oracle):
+    """The one-call frame entry (gi2d_render_*_fwd) gives the operators' bits; a rasterize call
+    after a projection that refilled the lists, without the binning call, is refused."""
+    import ctypes
+    from gaussianimage_amd import _lib
+    from gaussianimage_amd.pipeline import FramePipeline
+    H, W, N = 112, 144, 3000
+    for kind in ("cholesky", "rs"):
+        if kind == "cholesky":
+            means, a, col, op = synth.cholesky_inputs(N, seed=9, footprint=1.5)
+            b = None
+        else:
+            means, a, b, col, op = synth.rs_inputs(N, seed=9, footprint=1.5)
+        dev = [None if t is None else t.to(DEV).contiguous() for t in (means, a, b, col)]
+        opa = op.to(DEV)
+        tb = oracle.tile_bounds(H, W)
+        if kind == "cholesky":
+            proj = ops.project_gaussians_2d(dev[0], dev[1], H, W, tb)
+        else:
+            proj = ops.project_gaussians_2d_scale_rot(dev[0], dev[1], dev[2], H, W, tb)
+        ref = ops.rasterize_gaussians_sum(*proj, dev[3], opa, H, W, 16, 16)
+        pipe = FramePipeline(N, H, W, kind=kind, device=DEV)
+        for _ in range(3):  # first frame learns the shape synchronously, later ones do not
+            img = pipe.forward(dev[0], dev[1], dev[2], dev[3], opa.reshape(-1))
+            assert torch.equal(img, ref)
+        run = pipe.bind(dev[0], dev[1], dev[2], dev[3], opa.reshape(-1))
+        assert torch.equal(run(), ref)
+        for out, got in zip(proj, (pipe.xys, pipe.depths, pipe.radii, pipe.conics,
+                                   pipe.num_tiles_hit)):
+            assert torch.equal(out, got)
+        # projection with the workspace refills the lists; rasterizing before gi2d_bin_tiles
+        pipe.project(dev[0], dev[1], dev[2])
+        rc = _lib.lib.gi2d_rasterize_sum_fwd(
+            pipe.ws.handle, ops._ptr(pipe.xys), ops._ptr(pipe.conics), ops._ptr(dev[3]),
+            ops._ptr(opa), None, N, H, W, ctypes.byref(pipe.conv), ops._ptr(pipe.image),
+            ops._stream(torch.device(DEV)))
+        assert rc == _lib.GI2D_E_STATE
+        pipe.bin()
+        assert torch.equal(pipe.rasterize(dev[3], opa.reshape(-1)), ref)
