@@ -431,7 +431,10 @@ __device__ __forceinline__ void finalize_tile_words(int t, int n_raw, int C, int
 {
     tile_len[t] = n_raw;
     tile_count[(size_t)t * CNT_STRIDE] = 0;
-    if (2 * n_raw > C) atomicMax(&status->max_count, n_raw);  // rare by construction
+    // Raising the published maximum is rare: only lists past half the capacity try, and only
+    // those above the value already there reach the atomic (thousands of tiles hammering one
+    // word would otherwise serialise at the memory side).
+    if (2 * n_raw > C && n_raw > status->max_count) atomicMax(&status->max_count, n_raw);
     if (n_raw > C) status->overflow_gen = generation;
 }
 
