@@ -169,6 +169,17 @@ def bench_model_loops(name, device, steps):
         torch.cuda.synchronize()
         out["reference_fps_loop"] = 100 / (time.perf_counter() - t0)
     if kind == "cholesky":
+        # the same three images from one multi-set launch instead of three passes
+        model.passes = "fused"
+        with torch.no_grad():
+            for _ in range(10):
+                model()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                model()
+            torch.cuda.synchronize()
+            out["reference_fps_loop_fused_passes"] = 100 / (time.perf_counter() - t0)
         model.passes = 1
         model.train()
         for _ in range(5):
@@ -329,6 +340,11 @@ def main():
 
         ex["project_bin_ms"] = bench_region(proj_bin, k, 5)
         ex["rasterize_ms"] = bench_region(lambda: pipe.rasterize(col, op), k, 5)
+        three = [col, torch.rand_like(col) * 0.5, torch.ones_like(col)]
+        ex["rasterize_3sets_one_launch_ms"] = bench_region(
+            lambda: pipe.rasterize_multi(three, op), k, 5)
+        ex["rasterize_3sets_three_launches_ms"] = bench_region(
+            lambda: [pipe.rasterize(c, op) for c in three], k, 5)
         ex["bwd_only_ms"] = bench_region(
             lambda: pipe.backward(means, cov_a, cov_b, col, op, v_img), k, 5)
         # Pair evaluations per second against the fp32 vector peak: the inner loop is VALU

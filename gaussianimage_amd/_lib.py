@@ -27,6 +27,7 @@ BIN_NOGROW = 4
 OPT_CULL = 1
 
 BLOCK = 16
+MAX_COLOR_SETS = 3  # GI2D_MAX_COLOR_SETS
 
 
 class AdanHyper(ctypes.Structure):
@@ -67,6 +68,8 @@ SIGNATURES = {
     "gi2d_bin_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gi2d_copy_bins": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "gi2d_rasterize_sum_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp]),
+    "gi2d_rasterize_sum_fwd_multi": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _convp, _vp,
+                                          _vp]),
     "gi2d_render_cholesky_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_render_rs_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,

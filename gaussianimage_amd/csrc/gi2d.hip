@@ -544,16 +544,30 @@ __device__ __forceinline__ int xcd_tile(int bid, int T)
 // utils.py:24-25): clamp to [0,1], L2 loss against the target (stored [3,H,W] like the model's
 // gt_image), and the gradient of the mean-squared error with respect to the unclamped image
 // written to `v_img` [H,W,3]; each tile leaves its sum of squared errors in loss_part[tile].
-template <bool FINALIZE, bool L2>
+//
+// SETS > 1 renders further colour sets of the same Gaussians in the same pass (the model's
+// forward rasterises three colour tensors over one projection,
+// gaussianimage_cholesky.py:81-97): the geometry, the culling and the alpha of a (pixel,
+// Gaussian) pair are computed once and feed 3*SETS accumulators.
+struct ExtraSets {
+    const float *colors[2];  // [N,3] each
+    float *out[2];           // [H,W,3] each
+};
+
+template <bool FINALIZE, bool L2, int SETS>
 __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, float bg0, float bg1, float bg2, int H, int W, int tiles_x,
     int row0, int T, gi2d_conv cv, int cull, DevStatus *status, long long generation,
     float *__restrict__ out, const float *__restrict__ gt, float *__restrict__ v_img,
-    float *__restrict__ loss_part)
+    float *__restrict__ loss_part, ExtraSets extra)
 {
+    static_assert(SETS >= 1 && SETS <= 3 && !(L2 && SETS > 1), "unsupported variant");
+    constexpr int NX = 3 * (SETS - 1);          // extra colour floats per entry
+    constexpr int NX4 = (NX + 3) / 4;           // ... in float4 records
     __shared__ __attribute__((aligned(16))) int smem[FWD_LDS_INTS];
+    __shared__ float4 s_x[NX4 ? NX4 * 256 : 1];  // extra sets: record q of entry k at [q*256+k]
     float4 *s_a = reinterpret_cast<float4 *>(smem);         // gx, gy, -0.5*a*log2e, -b*log2e
     float4 *s_b = reinterpret_cast<float4 *>(smem + 1024);  // -0.5*c*log2e, opacity, r, g
     float *s_c = reinterpret_cast<float *>(smem + 2048);    // b
@@ -573,6 +587,9 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     const int n_raw = FINALIZE ? tile_count[(size_t)t * CNT_STRIDE] : tile_len[t];
     const int n_all = min(n_raw, C);
     float r = 0.f, g = 0.f, b = 0.f;
+    float xacc[NX ? NX : 1];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) xacc[q] = 0.f;
     if (FINALIZE) {
         __syncthreads();  // every wave has read the counter before lane 0 returns it to zero
         if (n_all > 256) {  // long list: sort it where it lies before the batches are read
@@ -622,6 +639,16 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
             s_a[slot] = make_float4(gx, gy, (-0.5f * LOG2E) * ca, (-LOG2E) * cb);
             s_b[slot] = make_float4((-0.5f * LOG2E) * cc, op, colors[3 * gid], colors[3 * gid + 1]);
             s_c[slot] = colors[3 * gid + 2];
+            if (NX) {
+                float xc[NX4 ? 4 * NX4 : 1];
+#pragma unroll
+                for (int q = 0; q < 4 * NX4; ++q)
+                    xc[q] = q < NX ? extra.colors[q / 3][3 * gid + q % 3] : 0.f;
+#pragma unroll
+                for (int q = 0; q < NX4; ++q)
+                    s_x[q * 256 + slot] =
+                        make_float4(xc[4 * q], xc[4 * q + 1], xc[4 * q + 2], xc[4 * q + 3]);
+            }
             int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
             if (cull) support_rect(gx, gy, ca, cb, cc, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
             if (x0 <= x1 && y0 <= y1) {
@@ -650,6 +677,17 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
                 r = __builtin_fmaf(B.z, w, r);
                 g = __builtin_fmaf(B.w, w, g);
                 b = __builtin_fmaf(cb, w, b);
+                if (NX) {
+#pragma unroll
+                    for (int q = 0; q < NX4; ++q) {
+                        const float4 X = s_x[q * 256 + k];
+                        const float xv[4] = {X.x, X.y, X.z, X.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (4 * q + u < NX)
+                                xacc[4 * q + u] = __builtin_fmaf(xv[u], w, xacc[4 * q + u]);
+                    }
+                }
             }
         }
     }
@@ -663,6 +701,15 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
         o[0] = r;
         o[1] = g;
         o[2] = b;
+    }
+    if (NX && inside) {
+        const float bgs[3] = {bg0, bg1, bg2};
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            float v = xacc[q] + cv.bg_weight * bgs[q % 3];
+            if (n_raw > C) v = __builtin_nanf("");
+            extra.out[q / 3][3 * pix + q % 3] = v;
+        }
     }
     if (L2) {
         float sq = 0.f;
@@ -1629,10 +1676,12 @@ static int check_raster_args(gi2d_workspace *ws, int N, int H, int W, const gi2d
 }
 
 // gt / v_img / loss_part non-NULL selects the fitting epilogue (then out_img may be NULL).
+// sets = number of colour sets (1..3); sets beyond the first come in `extra`.
 static int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *conics,
                            const float *colors, const float *opacity, const float *background,
                            int N, int H, int W, const gi2d_conv *conv, float *out_img,
-                           const float *gt, float *v_img, float *loss_part, void *stream)
+                           const float *gt, float *v_img, float *loss_part, void *stream,
+                           int sets = 1, ExtraSets extra = ExtraSets())
 {
     int rc = check_raster_args(ws, N, H, W, conv);
     if (rc != GI2D_OK) return rc;
@@ -1644,7 +1693,7 @@ static int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *co
         return GI2D_OK;
     }
     const bool l2 = gt != nullptr;
-    if (l2 && (!v_img || !loss_part)) return GI2D_E_INVALID;
+    if (l2 && (!v_img || !loss_part || sets != 1)) return GI2D_E_INVALID;
     if ((!out_img && !l2) || (N > 0 && (!xys || !conics || !colors || !opacity)))
         return GI2D_E_INVALID;
     if (conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
@@ -1656,12 +1705,19 @@ static int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *co
     }
 #define GI2D_RASTER_ARGS ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, conics, colors, \
                          opacity, bg[0], bg[1], bg[2], H, W, ws->tiles_x, ws->bin_row0, T, *conv, \
-                         ws->cull, ws->d_status, ws->generation, out_img, gt, v_img, loss_part
+                         ws->cull, ws->d_status, ws->generation, out_img, gt, v_img, loss_part, \
+                         extra
     const bool fin = ws->lists_raw;
-    if (fin && l2) rasterize_sum_fwd_kernel<true, true><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
-    else if (fin) rasterize_sum_fwd_kernel<true, false><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
-    else if (l2) rasterize_sum_fwd_kernel<false, true><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
-    else rasterize_sum_fwd_kernel<false, false><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+    if (sets == 3) {
+        if (fin) rasterize_sum_fwd_kernel<true, false, 3><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+        else rasterize_sum_fwd_kernel<false, false, 3><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+    } else if (sets == 2) {
+        if (fin) rasterize_sum_fwd_kernel<true, false, 2><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+        else rasterize_sum_fwd_kernel<false, false, 2><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+    } else if (fin && l2) rasterize_sum_fwd_kernel<true, true, 1><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+    else if (fin) rasterize_sum_fwd_kernel<true, false, 1><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+    else if (l2) rasterize_sum_fwd_kernel<false, true, 1><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+    else rasterize_sum_fwd_kernel<false, false, 1><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
 #undef GI2D_RASTER_ARGS
     if (fin) {
         ws->lists_raw = false;
@@ -1677,6 +1733,25 @@ int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *co
 {
     return raster_fwd_impl(ws, xys, conics, colors, opacity, background, N, H, W, conv, out_img,
                            nullptr, nullptr, nullptr, stream);
+}
+
+int gi2d_rasterize_sum_fwd_multi(gi2d_workspace *ws, const float *xys, const float *conics,
+                                 int num_sets, const float *const *colors, const float *opacity,
+                                 const float *background, int N, int H, int W,
+                                 const gi2d_conv *conv, float *const *out_imgs, void *stream)
+{
+    if (num_sets < 1 || num_sets > GI2D_MAX_COLOR_SETS || !colors || !out_imgs)
+        return GI2D_E_INVALID;
+    ExtraSets extra = ExtraSets();
+    for (int s = 0; s < num_sets; ++s) {
+        if (!out_imgs[s] || (N > 0 && !colors[s])) return GI2D_E_INVALID;
+        if (s > 0) {
+            extra.colors[s - 1] = colors[s];
+            extra.out[s - 1] = out_imgs[s];
+        }
+    }
+    return raster_fwd_impl(ws, xys, conics, colors[0], opacity, background, N, H, W, conv,
+                           out_imgs[0], nullptr, nullptr, nullptr, stream, num_sets, extra);
 }
 
 // Backward pass 1 (per-tile partial sums into the slab); shared by the operator backward and

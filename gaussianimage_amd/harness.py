@@ -18,6 +18,8 @@ from gsplat.project_gaussians_2d import project_gaussians_2d
 from gsplat.project_gaussians_2d_scale_rot import project_gaussians_2d_scale_rot
 from gsplat.rasterize_sum import rasterize_gaussians_sum
 
+from .ops import rasterize_gaussians_sum_multi
+
 from .adan import Adan
 
 
@@ -63,7 +65,8 @@ class CholeskyImageModel(_Base):
         self._cholesky = nn.Parameter(torch.rand(num_points, 3))
         self.register_buffer('cholesky_bound', torch.tensor([0.5, 0, 0.5]).view(1, 3))
         self.random_colors = torch.rand(num_points, 3)
-        self.passes = passes  # the reference's forward() makes 3; 1 = the render alone
+        self.passes = passes  # the reference's forward() makes 3; 1 = the render alone;
+        # "fused" = the three images from one multi-set launch
         self._finish()
 
     def forward(self):
@@ -73,6 +76,15 @@ class CholeskyImageModel(_Base):
         colors, opacities = self._features_dc, self._opacity.clone()
         args = (self.xys, depths, self.radii, conics, num_tiles_hit)
         kw = dict(background=self.background, return_alpha=False)
+        if self.passes == "fused":
+            # the same three images from one launch
+            geom = self.random_colors.to(self.xys.device) * 0.5
+            img, gauss, alpha = rasterize_gaussians_sum_multi(
+                *args, [colors, geom, torch.ones_like(colors)], opacities, self.H, self.W,
+                self.BLOCK_H, self.BLOCK_W, background=self.background)
+            alpha = alpha.mean(dim=-1, keepdim=True)
+            return {"render": self._image(img), "gauss_render": self._image(gauss),
+                    "alpha_map": alpha.view(-1, self.H, self.W, 1).permute(0, 3, 1, 2).contiguous()}
         out = {"render": self._image(rasterize_gaussians_sum(
             *args, colors, opacities, self.H, self.W, self.BLOCK_H, self.BLOCK_W, **kw))}
         if self.passes >= 3:

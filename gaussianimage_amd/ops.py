@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import BLOCK, Conv, check, default_conv, lib
 
 __all__ = ["project_gaussians_2d", "project_gaussians_2d_scale_rot", "rasterize_gaussians_sum",
-           "Workspace", "get_workspace", "set_conventions", "get_conventions"]
+           "rasterize_gaussians_sum_multi", "Workspace", "get_workspace", "set_conventions", "get_conventions"]
 
 _CONV = default_conv()
 
@@ -287,6 +287,74 @@ class _RasterizeGaussiansSum(torch.autograd.Function):
                 None)
 
 
+class _RasterizeGaussiansSumMulti(torch.autograd.Function):
+    """Several colour sets over one set of Gaussians in one forward launch; the backward runs
+    the single-set backward once per set that received a gradient and adds the geometry terms."""
+
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width,
+                background, *colors):
+        dev = xys.device
+        N = xys.shape[0]
+        xys_c = xys.detach()
+        if xys_c.dtype != torch.float32 or not xys_c.is_contiguous():
+            xys_c = _f32c(xys)
+        radii_c = radii if (radii.dtype == torch.int32 and radii.is_contiguous()) else \
+            radii.to(torch.int32).contiguous()
+        con = _f32c(conics)
+        cols = [_f32c(c) for c in colors]
+        opa = _f32c(opacity).reshape(-1)
+        bg = _f32c(background)
+        ws = get_workspace(dev)
+        ws.bin(xys_c, radii_c, img_height, img_width)
+        outs = [torch.empty(img_height, img_width, 3, dtype=torch.float32, device=dev)
+                for _ in cols]
+        S = len(cols)
+        col_ptrs = (ctypes.c_void_p * S)(*[c.data_ptr() for c in cols])
+        out_ptrs = (ctypes.c_void_p * S)(*[o.data_ptr() for o in outs])
+        check(lib.gi2d_rasterize_sum_fwd_multi(ws.handle, _ptr(xys_c), _ptr(con), S, col_ptrs,
+                                               _ptr(opa), _ptr(bg), N, img_height, img_width,
+                                               ctypes.byref(_CONV), out_ptrs, _stream(dev)),
+              "gi2d_rasterize_sum_fwd_multi")
+        ctx.save_for_backward(xys_c, radii_c, con, opa, *cols)
+        ctx.hw = (img_height, img_width)
+        ctx.opacity_shape = opacity.shape
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *v_outs):
+        xys, radii, con, opa, *cols = ctx.saved_tensors
+        H, W = ctx.hw
+        N = xys.shape[0]
+        dev = xys.device
+        ws = get_workspace(dev)
+        ws.bin(xys, radii, H, W)
+        f32 = torch.float32
+        v_xy = v_con = v_opa = None
+        v_cols = []
+        for col, v_out in zip(cols, v_outs):
+            if v_out is None:
+                v_cols.append(None)
+                continue
+            v_out = _f32c(v_out)
+            g_xy = torch.empty(N, 2, dtype=f32, device=dev)
+            g_con = torch.empty(N, 3, dtype=f32, device=dev)
+            g_col = torch.empty(N, 3, dtype=f32, device=dev)
+            g_opa = torch.empty(N, dtype=f32, device=dev)
+            check(lib.gi2d_rasterize_sum_bwd(ws.handle, _ptr(xys), _ptr(radii), _ptr(con),
+                                             _ptr(col), _ptr(opa), N, H, W, ctypes.byref(_CONV),
+                                             _ptr(v_out), _ptr(g_xy), _ptr(g_con), _ptr(g_col),
+                                             _ptr(g_opa), _stream(dev)), "gi2d_rasterize_sum_bwd")
+            v_cols.append(g_col)
+            if v_xy is None:
+                v_xy, v_con, v_opa = g_xy, g_con, g_opa
+            else:
+                v_xy, v_con, v_opa = v_xy + g_xy, v_con + g_con, v_opa + g_opa
+        if v_opa is not None:
+            v_opa = v_opa.reshape(ctx.opacity_shape)
+        return (v_xy, None, None, v_con, None, v_opa, None, None, None, *v_cols)
+
+
 def project_gaussians_2d(means2d, L_elements, img_height, img_width, tile_bounds):
     """``gsplat.project_gaussians_2d.project_gaussians_2d`` of the reference
     (/root/reference/gaussianimage_cholesky.py:77).  Returns
@@ -350,3 +418,33 @@ def rasterize_gaussians_sum(xys, depths, radii, conics, num_tiles_hit, colors, o
                                              int(img_height), int(img_width), background)[..., 0]
         return out, alpha
     return out
+
+
+def rasterize_gaussians_sum_multi(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
+                                  img_height, img_width, BLOCK_H=16, BLOCK_W=16, background=None):
+    """``rasterize_gaussians_sum`` for a list of up to 3 colour tensors ``[N,3]`` over the same
+    Gaussians, in one launch; returns a tuple of ``[H,W,3]`` images, each bit-identical to the
+    single-set call.  No counterpart in the reference's ``gsplat``: it is what the three
+    back-to-back passes of ``GaussianImage_Cholesky.forward``
+    (/root/reference/gaussianimage_cholesky.py:81-97) amount to.  Differentiable."""
+    colors = list(colors)
+    if not 1 <= len(colors) <= _lib.MAX_COLOR_SETS:
+        raise ValueError("between 1 and %d colour sets" % _lib.MAX_COLOR_SETS)
+    if opacity.ndimension() != 2:
+        raise ValueError("opacity must have dimensions (N, 1)")
+    N = xys.shape[0]
+    for c in colors:
+        if c.ndimension() != 2 or c.shape[1] != 3 or c.shape[0] != N:
+            raise ValueError("every colour set must have shape (N, 3)")
+    if int(BLOCK_H) != BLOCK or int(BLOCK_W) != BLOCK:
+        raise ValueError(f"tile size is fixed at {BLOCK}x{BLOCK} (the reference's train.py:54)")
+    _need_cuda("rasterize_gaussians_sum_multi", xys, conics, opacity, *colors)
+    if background is None:
+        background = torch.ones(3, dtype=torch.float32, device=xys.device)
+    if background.shape[0] != 3:
+        raise ValueError("background and colors must have the same number of channels")
+    for name, t in (("radii", radii), ("conics", conics), ("opacity", opacity)):
+        if t.shape[0] != N:
+            raise ValueError(f"{name} has {t.shape[0]} rows, xys has {N}")
+    return _RasterizeGaussiansSumMulti.apply(xys, depths, radii, conics, num_tiles_hit, opacity,
+                                             int(img_height), int(img_width), background, *colors)

@@ -87,6 +87,23 @@ class FramePipeline:
               "gi2d_rasterize_sum_fwd")
         return out
 
+    def rasterize_multi(self, colors, opacity, outs=None):
+        """Up to 3 colour tensors ``[N,3]`` over the current lists in one launch; returns the
+        list of ``[band_h, W, 3]`` images (the first defaults to the pipeline's own buffer)."""
+        S = len(colors)
+        if outs is None:
+            if len(getattr(self, "extra_images", ())) < S - 1:
+                self.extra_images = [torch.empty_like(self.image) for _ in range(S - 1)]
+            outs = [self.image] + self.extra_images[:S - 1]
+        col_ptrs = (ctypes.c_void_p * S)(*[c.data_ptr() for c in colors])
+        out_ptrs = (ctypes.c_void_p * S)(*[o.data_ptr() for o in outs])
+        check(lib.gi2d_rasterize_sum_fwd_multi(self.ws.handle, _ptr(self.xys), _ptr(self.conics),
+                                               S, col_ptrs, _ptr(opacity), _ptr(self.background),
+                                               self.N, self.H, self.W, ctypes.byref(self.conv),
+                                               out_ptrs, _stream(self.device)),
+              "gi2d_rasterize_sum_fwd_multi")
+        return outs
+
     def forward(self, means, cov_a, cov_b, colors, opacity, out=None, events=None):
         """project -> bin -> rasterize in one C call; returns the (band of the) image,
         ``[band_h, W, 3]``.  ``events``: optional pair of ``torch.cuda.Event`` recorded right

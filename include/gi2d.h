@@ -127,6 +127,18 @@ int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *co
                            int N, int H, int W, const gi2d_conv *conv, float *out_img,
                            void *stream);
 
+/* The same forward for num_sets (1..GI2D_MAX_COLOR_SETS) colour tensors over one
+ * set of Gaussians, in one pass: colors[s] is [N,3], out_imgs[s] is [H,W,3]
+ * (host arrays of device pointers).  Replaces the three rasterize_gaussians_sum
+ * calls of GaussianImage_Cholesky.forward (gaussianimage_cholesky.py:81-97:
+ * features, gauss_colors, 1-gauss_colors) with a single launch; each image is
+ * bit-identical to the one gi2d_rasterize_sum_fwd gives for that colour set. */
+#define GI2D_MAX_COLOR_SETS 3
+int gi2d_rasterize_sum_fwd_multi(gi2d_workspace *ws, const float *xys, const float *conics,
+                                 int num_sets, const float *const *colors, const float *opacity,
+                                 const float *background, int N, int H, int W,
+                                 const gi2d_conv *conv, float *const *out_imgs, void *stream);
+
 /* Its backward (gaussianimage_cholesky.py:116): v_out[H,W,3] ->
  * v_xys[N,2], v_conics[N,3], v_colors[N,3], v_opacity[N].  Deterministic: no
  * floating-point atomics. */

@@ -487,3 +487,82 @@ def test_frame_pipeline_equals_operator_path_and_state_errors(ops, oracle):
         assert rc == _lib.GI2D_E_STATE
         pipe.bin()
         assert torch.equal(pipe.rasterize(dev[3], opa.reshape(-1)), ref)
+
+
+@pytest.mark.parametrize("H,W,N,seed,fp,sets", [(80, 96, 512, 1, 1.0, 3), (33, 50, 300, 2, 2.0, 2),
+                                                (64, 64, 3000, 5, 6.0, 3), (48, 64, 64, 0, 1.0, 1)])
+def test_multi_set_pass_equals_separate_passes(ops, oracle, H, W, N, seed, fp, sets):
+    """The one-launch rendering of several colour sets (the model's three passes,
+    gaussianimage_cholesky.py:81-97) gives, bit for bit, the images of separate calls, both as
+    the first pass after a binning (sorting variant) and as a later one; the oracle confirms
+    the values; gradients are those of the separate calls."""
+    means, L, col, op, proj, ws = _project_and_bin(ops, oracle, H, W, N, seed, fp)
+    g = torch.Generator().manual_seed(seed + 7)
+    op = (0.2 + 0.8 * torch.rand(N, 1, generator=g)).to(DEV)
+    cols = [col.to(DEV), (torch.rand(N, 3, generator=g) * 0.5).to(DEV),
+            torch.ones(N, 3, device=DEV)][:sets]
+    xys, depths, radii, conics, nth = proj
+    single = [ops.rasterize_gaussians_sum(xys, depths, radii, conics, nth, c, op, H, W, 16, 16)
+              for c in cols]
+    later = ops.rasterize_gaussians_sum_multi(xys, depths, radii, conics, nth, cols, op, H, W)
+    ws.bin(xys, radii, H, W, force=True)  # fresh lists: the multi pass sorts them itself
+    first = ops.rasterize_gaussians_sum_multi(xys, depths, radii, conics, nth, cols, op, H, W)
+    assert len(later) == len(first) == sets
+    for s in range(sets):
+        assert torch.equal(later[s], single[s]), s
+        assert torch.equal(first[s], single[s]), s
+    offs, ids = oracle.bin_tiles(_np(xys), _np(radii), H, W)
+    for s in range(sets):
+        ref, margin = oracle.rasterize_sum_fwd(_np(xys), _np(conics), _np(cols[s]), _np(op), H, W,
+                                               offs, ids, want_margin=True)
+        ok = margin > 1e-4
+        # (the dense case piles hundreds of Gaussians on a pixel: values of ~100, whose float
+        # spacing alone is 8e-6, so the bound is taken relative to the image's scale there)
+        assert np.abs(_np(first[s]) - ref)[ok].max() <= IMG_ATOL * max(1.0, np.abs(ref).max())
+    # gradients: sum over the sets of the single-set gradients
+    v = [torch.randn(H, W, 3, generator=g).to(DEV) for _ in range(sets)]
+
+    def grads(multi):
+        leaves = [xys.detach().clone().requires_grad_(True),
+                  conics.detach().clone().requires_grad_(True), op.clone().requires_grad_(True)]
+        cl = [c.clone().requires_grad_(True) for c in cols]
+        if multi:
+            imgs = ops.rasterize_gaussians_sum_multi(leaves[0], depths, radii, leaves[1], nth, cl,
+                                                     leaves[2], H, W)
+        else:
+            imgs = [ops.rasterize_gaussians_sum(leaves[0], depths, radii, leaves[1], nth, c,
+                                                leaves[2], H, W, 16, 16) for c in cl]
+        sum((i * w).sum() for i, w in zip(imgs, v)).backward()
+        return [t.grad for t in leaves + cl]
+
+    for a, b in zip(grads(True), grads(False)):
+        assert a.shape == b.shape
+        assert _maxrel(_np(a), _np(b)) <= 1e-6
+
+
+def test_multi_set_argument_errors(ops, oracle):
+    H, W, N = 32, 32, 40
+    means, L, col, op, proj, ws = _project_and_bin(ops, oracle, H, W, N, 0, 1.0)
+    c, o = col.to(DEV), op.to(DEV)
+    with pytest.raises(ValueError):
+        ops.rasterize_gaussians_sum_multi(*proj, [], o, H, W)
+    with pytest.raises(ValueError):
+        ops.rasterize_gaussians_sum_multi(*proj, [c] * 4, o, H, W)
+    with pytest.raises(ValueError):
+        ops.rasterize_gaussians_sum_multi(*proj, [c, c[:, :2]], o, H, W)
+    with pytest.raises(RuntimeError):
+        ops.rasterize_gaussians_sum_multi(*[p.cpu() for p in proj], [col], op, H, W)
+
+
+def test_harness_fused_passes_equal_the_three_pass_forward(ops, oracle):
+    from gaussianimage_amd.harness import CholeskyImageModel
+    torch.manual_seed(3)
+    a = CholeskyImageModel(2000, 96, 128, DEV, passes=3)
+    b = CholeskyImageModel(2000, 96, 128, DEV, passes="fused")
+    b.load_state_dict(a.state_dict())
+    b.random_colors = a.random_colors
+    with torch.no_grad():
+        oa, ob = a(), b()
+    assert set(oa) == set(ob) == {"render", "gauss_render", "alpha_map"}
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
