@@ -193,6 +193,55 @@ def bench_model_loops(name, device, steps):
     return out
 
 
+def bench_decode(name, device, steps):
+    """The codec's decoding-speed loop (/root/reference/test_quantize.py:69-74: 100 x
+    decompress_wo_ec(encoding_dict), wall clock): the fused two-launch decode, and the same
+    decode written the reference's way -- torch expressions for the de-quantisation and the
+    code-vector lookup, the drop-in operators, clamp / view / permute."""
+    from gaussianimage_amd import codec, ops
+    H, W, N, kind, fp = WORKLOADS[name]
+    enc, q = codec.synthetic_encoding(N, kind, seed=1, footprint=fp)
+    dec = codec.CodecDecoder(enc, q, H, W, kind=kind, device=device)
+    out = {}
+
+    def loop(fn, n):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return n / (time.perf_counter() - t0)
+
+    out["decode_fps_fused"] = loop(dec.decode, max(steps, 100))
+    xyz, idx, cb = dec.xyz, dec.index.long(), dec.codebooks
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    bound = torch.tensor([0.5, 0, 0.5] if kind == "cholesky" else [0.5, 0.5],
+                         device=device).view(1, -1)
+
+    def reference_style():
+        means = torch.tanh(xyz.float())
+        colors = 0
+        for i in range(cb.shape[0]):
+            colors = colors + cb[i][idx[:, i]]
+        if kind == "cholesky":
+            L = dec.code_a * dec.scale_a + dec.beta_a + bound
+            proj = ops.project_gaussians_2d(means, L, H, W, tb)
+        else:
+            sc = torch.abs(dec.code_a * dec.scale_a + dec.beta_a + bound)
+            rot = dec.code_b * dec.scale_b + dec.beta_b
+            proj = ops.project_gaussians_2d_scale_rot(means, sc, rot, H, W, tb)
+        img = ops.rasterize_gaussians_sum(*proj, colors, dec.opacity, H, W, 16, 16,
+                                          background=dec.background, return_alpha=False)
+        img = torch.clamp(img, 0, 1)
+        return img.view(-1, H, W, 3).permute(0, 3, 1, 2).contiguous()
+
+    with torch.no_grad():
+        out["decode_fps_reference_style_loop"] = loop(reference_style, 100)
+    return out
+
+
 def bench_concurrent(name, inputs, device, steps, streams=4):
     """Throughput with several independent frames in flight: `streams` pipelines, each with its
     own workspace and HIP stream (default priority), frames issued round-robin.  A single
@@ -353,6 +402,7 @@ def main():
         ex["pair_evals_per_s"] = pairs / (raster_avg_ms * 1e-3)
         ex.update(bench_concurrent(args.workload, inputs, device, max(args.steps, 200)))
         ex.update(bench_model_loops(args.workload, device, k))
+        ex.update(bench_decode(args.workload, device, k))
         ex.update(bench_fused_fit(args.workload, device, max(k, 100)))
         result["extras"] = ex
     if not args.no_cpu_baseline and rank == 0 and world == 1:

@@ -28,6 +28,7 @@ OPT_CULL = 1
 
 BLOCK = 16
 MAX_COLOR_SETS = 3  # GI2D_MAX_COLOR_SETS
+MAX_VQ_LAYERS = 8   # GI2D_MAX_VQ_LAYERS
 
 
 class AdanHyper(ctypes.Structure):
@@ -36,6 +37,14 @@ class AdanHyper(ctypes.Structure):
                 ("beta3", ctypes.c_double), ("eps", ctypes.c_double),
                 ("weight_decay", ctypes.c_double), ("no_prox", ctypes.c_int),
                 ("step", ctypes.c_int)]
+
+
+class Codec(ctypes.Structure):
+    """Mirror of ``gi2d_codec``."""
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("xyz_half", "cov_a_code", "cov_a_scale", "cov_a_beta", "cov_b_code",
+                 "cov_b_scale", "cov_b_beta", "color_index", "codebooks")] + \
+               [("num_quantizers", ctypes.c_int), ("codebook_size", ctypes.c_int)]
 
 
 class Conv(ctypes.Structure):
@@ -74,6 +83,9 @@ SIGNATURES = {
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_render_rs_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gi2d_decode_params": (_i, [_i, ctypes.POINTER(Codec), _i, _vp, _vp, _vp, _vp, _vp]),
+    "gi2d_decode_render": (_i, [_vp, _i, ctypes.POINTER(Codec), _vp, _vp, _i, _i, _i, _convp, _vp,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_fit_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_fit_backward_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,

@@ -17,6 +17,7 @@
 // 768x512 frame with 30k Gaussians is only a few us of arithmetic, so the design minimises
 // launches and dependent rounds rather than bytes.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <limits.h>
 #include <math.h>
 #include <stdint.h>
@@ -246,6 +247,110 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     float syy = s * s * q1 + c * c * q2;
     project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths, radii,
                  conics, num_tiles_hit, tile_count, seg, C, row0, row1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Codec decode (decompress_wo_ec, gaussianimage_cholesky.py:161-166 / gaussianimage_rs.py:132-139):
+//   means    = tanh(float(xyz_half))
+//   cholesky = code * scale + beta, then + (0.5, 0, 0.5)       (quantize.py:86-87)
+//   scaling  = |code * scale + beta + 0.5|,  rotation = code * scale + beta
+//   colors   = sum over the residual-VQ layers q of codebook[q][index[g][q]]   (quantize.py:146-150)
+// Each product, sum and bound is rounded on its own, in the reference's order.  An index
+// outside the codebook is clamped into it (a corrupt stream gives wrong colours, not a fault).
+// ------------------------------------------------------------------------------------------
+struct DecodedGaussian {
+    float mx, my, a0, a1, a2, b0, col[3];
+};
+
+template <bool RS>
+__device__ __forceinline__ DecodedGaussian decode_gaussian(const gi2d_codec &cd, int g)
+{
+    DecodedGaussian d;
+    const __half2 h = reinterpret_cast<const __half2 *>(cd.xyz_half)[g];
+    d.mx = tanhf(__low2float(h));
+    d.my = tanhf(__high2float(h));
+    if (RS) {
+        d.a0 = fabsf((cd.cov_a_code[2 * g] * cd.cov_a_scale[0] + cd.cov_a_beta[0]) + 0.5f);
+        d.a1 = fabsf((cd.cov_a_code[2 * g + 1] * cd.cov_a_scale[1] + cd.cov_a_beta[1]) + 0.5f);
+        d.a2 = 0.f;
+        d.b0 = cd.cov_b_code[g] * cd.cov_b_scale[0] + cd.cov_b_beta[0];
+    } else {
+        d.a0 = (cd.cov_a_code[3 * g] * cd.cov_a_scale[0] + cd.cov_a_beta[0]) + 0.5f;
+        d.a1 = (cd.cov_a_code[3 * g + 1] * cd.cov_a_scale[1] + cd.cov_a_beta[1]) + 0.0f;
+        d.a2 = (cd.cov_a_code[3 * g + 2] * cd.cov_a_scale[2] + cd.cov_a_beta[2]) + 0.5f;
+        d.b0 = 0.f;
+    }
+    d.col[0] = d.col[1] = d.col[2] = 0.f;
+    for (int q = 0; q < cd.num_quantizers; ++q) {
+        int k = cd.color_index[(size_t)g * cd.num_quantizers + q];
+        k = min(max(k, 0), cd.codebook_size - 1);
+        const float *e = cd.codebooks + ((size_t)q * cd.codebook_size + k) * 3;
+        d.col[0] += e[0];
+        d.col[1] += e[1];
+        d.col[2] += e[2];
+    }
+    return d;
+}
+
+// The decoded operator inputs as tensors (what the reference's torch expressions produce).
+template <bool RS>
+__global__ __launch_bounds__(256) void decode_params_kernel(gi2d_codec cd, int N,
+                                                            float *__restrict__ means,
+                                                            float *__restrict__ cov_a,
+                                                            float *__restrict__ cov_b,
+                                                            float *__restrict__ colors)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const DecodedGaussian d = decode_gaussian<RS>(cd, g);
+    means[2 * g] = d.mx;
+    means[2 * g + 1] = d.my;
+    if (RS) {
+        cov_a[2 * g] = d.a0;
+        cov_a[2 * g + 1] = d.a1;
+        cov_b[g] = d.b0;
+    } else {
+        cov_a[3 * g] = d.a0;
+        cov_a[3 * g + 1] = d.a1;
+        cov_a[3 * g + 2] = d.a2;
+    }
+    colors[3 * g] = d.col[0];
+    colors[3 * g + 1] = d.col[1];
+    colors[3 * g + 2] = d.col[2];
+}
+
+// Decode fused into the projection: the frame's first launch reads the coded attributes, leaves
+// the decoded colours for the rasteriser and fills the tile lists.
+template <bool RS>
+__global__ __launch_bounds__(256) void project_decode_fwd_kernel(
+    gi2d_codec cd, float *__restrict__ colors, int N, int H, int W, int tiles_x, int tiles_y,
+    float center_bias, float *__restrict__ xys, float *__restrict__ depths,
+    int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
+    int *tile_count, int *seg, int C, int row0, int row1, const DevStatus *status,
+    volatile long long *h_status, long long generation)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
+    if (g >= N) return;
+    const DecodedGaussian d = decode_gaussian<RS>(cd, g);
+    colors[3 * g] = d.col[0];
+    colors[3 * g + 1] = d.col[1];
+    colors[3 * g + 2] = d.col[2];
+    float sxx, sxy, syy;
+    if (RS) {
+        float s, c;
+        sincosf(d.b0, &s, &c);
+        const float q1 = d.a0 * d.a0, q2 = d.a1 * d.a1;
+        sxx = c * c * q1 + s * s * q2;
+        sxy = c * s * (q1 - q2);
+        syy = s * s * q1 + c * c * q2;
+    } else {
+        sxx = d.a0 * d.a0;
+        sxy = d.a0 * d.a1;
+        syy = d.a1 * d.a1 + d.a2 * d.a2;
+    }
+    project_tail(g, d.mx, d.my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths,
+                 radii, conics, num_tiles_hit, tile_count, seg, C, row0, row1);
 }
 
 // Binning from caller-made xys / radii (no projection in front of it).
@@ -552,6 +657,10 @@ __device__ __forceinline__ int xcd_tile(int bid, int T)
 struct ExtraSets {
     const float *colors[2];  // [N,3] each
     float *out[2];           // [H,W,3] each
+    // optional second form of the first image: clamped to [0,1] and planar, [3][rows][W] -- the
+    // model's "render" tensor (gaussianimage_cholesky.py:83-84) without the torch ops behind it
+    float *out_chw;
+    size_t chw_plane;        // rows * W of the band being rendered
 };
 
 template <bool FINALIZE, bool L2, int SETS>
@@ -701,6 +810,13 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
         o[0] = r;
         o[1] = g;
         o[2] = b;
+    }
+    if (inside && extra.out_chw != nullptr) {
+        float *o = extra.out_chw + pix;
+        // torch.clamp keeps a NaN (the overflow marker must survive); fmin/fmax would drop it
+        o[0] = r != r ? r : fminf(fmaxf(r, 0.f), 1.f);
+        o[extra.chw_plane] = g != g ? g : fminf(fmaxf(g, 0.f), 1.f);
+        o[2 * extra.chw_plane] = b != b ? b : fminf(fmaxf(b, 0.f), 1.f);
     }
     if (NX && inside) {
         const float bgs[3] = {bg0, bg1, bg2};
@@ -1416,11 +1532,36 @@ static int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hi
 
 // kind 0 = Cholesky (cov_a = L[N,3]), 1 = rotation-scale (cov_a = scales[N,2], cov_b = rotation).
 // raw = the model's raw parameters are given and activated inside the kernel.
+static int check_codec(int kind, const gi2d_codec *cd, int N)
+{
+    if ((kind != 0 && kind != 1) || !cd || N < 0) return GI2D_E_INVALID;
+    if (cd->num_quantizers < 1 || cd->num_quantizers > GI2D_MAX_VQ_LAYERS || cd->codebook_size < 1)
+        return GI2D_E_INVALID;
+    if (N == 0) return GI2D_OK;
+    if (!cd->xyz_half || !cd->cov_a_code || !cd->cov_a_scale || !cd->cov_a_beta ||
+        !cd->color_index || !cd->codebooks)
+        return GI2D_E_INVALID;
+    if (kind == 1 && (!cd->cov_b_code || !cd->cov_b_scale || !cd->cov_b_beta))
+        return GI2D_E_INVALID;
+    return GI2D_OK;
+}
+
+// codec != NULL: the inputs are the coded attributes (means / cov_a / cov_b unused) and the
+// decoded colours are written to colors_out.
 static int project_impl(int kind, bool raw, const float *means, const float *cov_a,
                         const float *cov_b, int N, int H, int W, int tiles_x, int tiles_y,
                         const gi2d_conv *conv, float *xys, float *depths, int *radii,
-                        float *conics, int *num_tiles_hit, gi2d_workspace *ws, void *stream)
+                        float *conics, int *num_tiles_hit, gi2d_workspace *ws, void *stream,
+                        const gi2d_codec *codec = nullptr, float *colors_out = nullptr)
 {
+    if (codec) {
+        int rcc = check_codec(kind, codec, N);
+        if (rcc != GI2D_OK) return rcc;
+        if (N > 0 && !colors_out) return GI2D_E_INVALID;
+        means = reinterpret_cast<const float *>(codec->xyz_half);
+        cov_a = codec->cov_a_code;
+        cov_b = codec->cov_b_code;
+    }
     int rc = check_proj_args(means, cov_a, N, H, W, tiles_x, tiles_y, conv, xys, depths, radii,
                              conics, num_tiles_hit);
     if (rc != GI2D_OK) return rc;
@@ -1443,7 +1584,12 @@ static int project_impl(int kind, bool raw, const float *means, const float *cov
     const dim3 grid(cdiv(N, PG_THREADS)), block(PG_THREADS);
 #define GI2D_PROJ_ARGS N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii, conics, \
                        num_tiles_hit, cnt, seg, C, r0, r1, status, hs, gen
-    if (kind == 0) {
+    if (codec) {
+        if (kind == 0)
+            project_decode_fwd_kernel<false><<<grid, block, 0, st>>>(*codec, colors_out, GI2D_PROJ_ARGS);
+        else
+            project_decode_fwd_kernel<true><<<grid, block, 0, st>>>(*codec, colors_out, GI2D_PROJ_ARGS);
+    } else if (kind == 0) {
         if (raw)
             project_cholesky_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, GI2D_PROJ_ARGS);
         else
@@ -1694,8 +1840,13 @@ static int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *co
     }
     const bool l2 = gt != nullptr;
     if (l2 && (!v_img || !loss_part || sets != 1)) return GI2D_E_INVALID;
-    if ((!out_img && !l2) || (N > 0 && (!xys || !conics || !colors || !opacity)))
+    if ((!out_img && !l2 && !extra.out_chw) ||
+        (N > 0 && (!xys || !conics || !colors || !opacity)))
         return GI2D_E_INVALID;
+    if (extra.out_chw) {
+        const int y0 = ws->bin_row0 * GI2D_BLOCK;
+        extra.chw_plane = (size_t)(min(H, ws->bin_row1 * GI2D_BLOCK) - y0) * (size_t)W;
+    }
     if (conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
     float bg[3] = {0.f, 0.f, 0.f};
     if (conv->bg_weight != 0.0f) {
@@ -1819,14 +1970,16 @@ static int render_tail(gi2d_workspace *ws, int N, int H, int W, int tiles_x, int
                        const gi2d_conv *conv, const float *xys, const int *radii,
                        const float *conics, const float *colors, const float *opacity,
                        const float *background, float *out_img, void *ev_begin, void *ev_end,
-                       void *stream)
+                       void *stream, float *out_chw = nullptr)
 {
     int rc = gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
     if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
     const int late = rc;
     if (ev_begin) HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, (hipStream_t)stream));
-    rc = gi2d_rasterize_sum_fwd(ws, xys, conics, colors, opacity, background, N, H, W, conv,
-                                out_img, stream);
+    ExtraSets extra = ExtraSets();
+    extra.out_chw = out_chw;
+    rc = raster_fwd_impl(ws, xys, conics, colors, opacity, background, N, H, W, conv, out_img,
+                         nullptr, nullptr, nullptr, stream, 1, extra);
     if (rc != GI2D_OK) return rc;
     if (ev_end) HIP_TRY(hipEventRecord((hipEvent_t)ev_end, (hipStream_t)stream));
     return late;
@@ -1861,6 +2014,37 @@ int gi2d_render_rs_fwd(gi2d_workspace *ws, const float *means2d, const float *sc
     if (rc != GI2D_OK) return rc;
     return render_tail(ws, N, H, W, tiles_x, tiles_y, conv, xys, radii, conics, colors, opacity,
                        background, out_img, raster_begin_event, raster_end_event, stream);
+}
+
+int gi2d_decode_params(int kind, const gi2d_codec *codec, int N, float *means2d, float *cov_a,
+                       float *cov_b, float *colors, void *stream)
+{
+    int rc = check_codec(kind, codec, N);
+    if (rc != GI2D_OK) return rc;
+    if (N == 0) return GI2D_OK;
+    if (!means2d || !cov_a || !colors || (kind == 1 && !cov_b)) return GI2D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0)
+        decode_params_kernel<false><<<cdiv(N, 256), 256, 0, st>>>(*codec, N, means2d, cov_a, cov_b,
+                                                                  colors);
+    else
+        decode_params_kernel<true><<<cdiv(N, 256), 256, 0, st>>>(*codec, N, means2d, cov_a, cov_b,
+                                                                 colors);
+    return launch_status();
+}
+
+int gi2d_decode_render(gi2d_workspace *ws, int kind, const gi2d_codec *codec, const float *opacity,
+                       const float *background, int N, int H, int W, const gi2d_conv *conv,
+                       float *xys, float *depths, int *radii, float *conics, int *num_tiles_hit,
+                       float *colors, float *out_img, float *render_chw, void *stream)
+{
+    if (!ws || (!out_img && !render_chw)) return GI2D_E_INVALID;
+    const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
+    int rc = project_impl(kind, false, nullptr, nullptr, nullptr, N, H, W, tiles_x, tiles_y, conv,
+                          xys, depths, radii, conics, num_tiles_hit, ws, stream, codec, colors);
+    if (rc != GI2D_OK) return rc;
+    return render_tail(ws, N, H, W, tiles_x, tiles_y, conv, xys, radii, conics, colors, opacity,
+                       background, out_img, nullptr, nullptr, stream, render_chw);
 }
 
 static int adan_scalars(const gi2d_adan_hyper *hyper, AdanScalars &h)

@@ -210,6 +210,49 @@ int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_
                            float *const *exp_avg_sq, float *const *exp_avg_diff,
                            float *const *neg_pre_grad, const gi2d_adan_hyper *hyper, void *stream);
 
+/* ---- codec decode path ------------------------------------------------------
+ * The coded attributes of one image, as compress_wo_ec() leaves them
+ * (gaussianimage_cholesky.py:154-159, gaussianimage_rs.py:125-130) together
+ * with the quantizers' parameters; all device pointers.
+ *   xyz_half     [N,2] IEEE half: encoding_dict["xyz"]
+ *   cov_a_code   kind 0: [N,3] quant_cholesky_elements; kind 1: [N,2]
+ *                quant_scaling -- integer codes held as float32, as the
+ *                reference holds them (quantize.py:82-84)
+ *   cov_a_scale, cov_a_beta   [3] / [2]: UniformQuantizer.scale / .beta
+ *   cov_b_code   kind 1: [N,1] quant_rotation with cov_b_scale/_beta [1]; kind 0: unused
+ *   color_index  [N,Q] int32: feature_dc_index (Q residual-VQ layers)
+ *   codebooks    [Q,K,3]: layer._codebook.embed[0] of each layer (quantize.py:146-150)
+ */
+#define GI2D_MAX_VQ_LAYERS 8
+typedef struct gi2d_codec {
+    const uint16_t *xyz_half;
+    const float *cov_a_code, *cov_a_scale, *cov_a_beta;
+    const float *cov_b_code, *cov_b_scale, *cov_b_beta;
+    const int32_t *color_index;
+    const float *codebooks;
+    int num_quantizers; /* Q, 1..GI2D_MAX_VQ_LAYERS */
+    int codebook_size;  /* K */
+} gi2d_codec;
+
+/* The decoded operator inputs of decompress_wo_ec (gaussianimage_cholesky.py:
+ * 163-166, gaussianimage_rs.py:135-139): means2d = tanh(float(xyz)),
+ * kind 0: cov_a = cholesky_elements + cholesky_bound [N,3];
+ * kind 1: cov_a = |scaling + bound| [N,2], cov_b = rotation [N,1];
+ * colors[N,3] = sum of the layers' code vectors. */
+int gi2d_decode_params(int kind, const gi2d_codec *codec, int N, float *means2d, float *cov_a,
+                       float *cov_b, float *colors, void *stream);
+
+/* decompress_wo_ec as a whole (gaussianimage_cholesky.py:161-172,
+ * gaussianimage_rs.py:132-145; the loop test_quantize.py:71-74 times) in two
+ * launches: decode + projection + list filling, then rasterisation.  Outputs:
+ * the projection's tensors, the decoded colors[N,3], and the image as
+ * out_img[H,W,3] (unclamped, may be NULL) and/or render_chw[3,H,W] =
+ * clamp(out_img,0,1) permuted, the model's "render" (may be NULL). */
+int gi2d_decode_render(gi2d_workspace *ws, int kind, const gi2d_codec *codec, const float *opacity,
+                       const float *background, int N, int H, int W, const gi2d_conv *conv,
+                       float *xys, float *depths, int *radii, float *conics, int *num_tiles_hit,
+                       float *colors, float *out_img, float *render_chw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
