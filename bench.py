@@ -282,8 +282,28 @@ def bench_fused_fit(name, device, steps):
         fit.step(gt)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"fused_train_step_ms": ms, "fused_train_iters_per_s": 1e3 / ms,
-            "fused_train_psnr_after_%d_iters" % (steps + 10): fit.psnr()}
+    out = {"fused_train_step_ms": ms, "fused_train_iters_per_s": 1e3 / ms,
+           "fused_train_psnr_after_%d_iters" % (steps + 10): fit.psnr()}
+    # several images fitted at once (the reference fits the images of a dataset one after the
+    # other, /root/reference/train.py:306-316): one fitter per HIP stream, default priority
+    streams = 4
+    fits = []
+    for _ in range(streams):
+        st = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(st):
+            fits.append(FusedFitter(N, H, W, kind=kind, device=device, keep_image=False))
+    torch.cuda.synchronize()
+    for _ in range(5):
+        for f in fits:
+            f.step(gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for f in fits:
+            f.step(gt)
+    torch.cuda.synchronize()
+    out["fused_train_iters_per_s_%d_streams" % streams] = streams * steps / (time.perf_counter() - t0)
+    return out
 
 
 def main():
@@ -294,6 +314,8 @@ def main():
     ap.add_argument("--workload", default="kodak30k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--raster-ppl", type=int, default=0, choices=[0, 1, 2, 4],
+                    help="pixels per lane of the forward rasteriser (0 = the library's choice)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -328,6 +350,8 @@ def main():
     H, W, N, kind, fp = WORKLOADS[args.workload]
     inputs = make_inputs(args.workload, device, seed=1 + rank)
     pipe = FramePipeline(N, H, W, kind=kind, device=device)
+    if args.raster_ppl:
+        pipe.ws.set_raster_ppl(args.raster_ppl)
     pipe.forward(*inputs)
     I = pipe.intersections()
     P, T = H * W, pipe.tiles_x * pipe.tiles_y

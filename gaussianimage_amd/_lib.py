@@ -25,6 +25,7 @@ BIN_COUNTED = 2
 BIN_NOGROW = 4
 
 OPT_CULL = 1
+OPT_RASTER_PPL = 2
 
 BLOCK = 16
 MAX_COLOR_SETS = 3  # GI2D_MAX_COLOR_SETS

@@ -576,6 +576,17 @@ __global__ __launch_bounds__(WAVE) void finalize_tiles_kernel(int *tile_count, i
     if (lane == 0) finalize_tile_words(t, n_raw, C, tile_count, tile_len, status, generation);
 }
 
+// Copies every finalised list to its place in the compact id array (one wave per tile).
+__global__ __launch_bounds__(WAVE) void compact_lists_kernel(const int *__restrict__ seg, int C,
+                                                             const int *__restrict__ tile_len,
+                                                             const int *__restrict__ offsets,
+                                                             int *__restrict__ ids)
+{
+    const int t = blockIdx.x;
+    const int n = min(tile_len[t], C), off = offsets[t];
+    for (int k = threadIdx.x; k < n; k += WAVE) ids[off + k] = seg[(size_t)t * C + k];
+}
+
 // ------------------------------------------------------------------------------------------
 // support rectangle shared by the forward and the backward rasterizer
 // ------------------------------------------------------------------------------------------
@@ -643,6 +654,10 @@ __device__ __forceinline__ int xcd_tile(int bid, int T)
 // ids back for the later passes and the backward, and finalises the tile's words.
 // ------------------------------------------------------------------------------------------
 
+// Tile counts from which the forward rasteriser switches to 2 / 4 pixels per lane (measured on
+// MI355X: below ~2 resident workgroups per CU slot the 4-wave layout is faster).
+#define GI2D_PPL2_MIN_TILES 8192
+#define GI2D_PPL4_MIN_TILES INT_MAX  // never chosen automatically: 2 was the best large-frame shape
 #define FWD_LDS_INTS 2816  // 11 KB of LDS: the staging records, or the sort buffer of a long list
 
 // L2 = true adds the fitting loop's epilogue (gaussianimage_cholesky.py:83-85,104 with
@@ -663,8 +678,14 @@ struct ExtraSets {
     size_t chw_plane;        // rows * W of the band being rendered
 };
 
-template <bool FINALIZE, bool L2, int SETS>
-__global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
+//
+// PPL (pixels per lane) = 1, 2 or 4 shrinks the workgroup to 4, 2 or 1 waves, each wave
+// rendering PPL quadrants.  A frame of many sparse tiles is bound by the chain of dependent
+// memory rounds of each workgroup, not by arithmetic; smaller workgroups put 2x / 4x as many
+// tiles in flight per CU.  Every pixel still adds its Gaussians in list order, so all variants
+// give the same bits.
+template <bool FINALIZE, bool L2, int SETS, int PPL>
+__global__ __launch_bounds__(256 / PPL) void rasterize_sum_fwd_kernel(
     int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, float bg0, float bg1, float bg2, int H, int W, int tiles_x,
@@ -673,6 +694,8 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     float *__restrict__ loss_part, ExtraSets extra)
 {
     static_assert(SETS >= 1 && SETS <= 3 && !(L2 && SETS > 1), "unsupported variant");
+    static_assert(PPL == 1 || ((PPL == 2 || PPL == 4) && SETS == 1), "unsupported variant");
+    constexpr int BATCH = 256 / PPL;            // lanes of the workgroup = entries staged at once
     constexpr int NX = 3 * (SETS - 1);          // extra colour floats per entry
     constexpr int NX4 = (NX + 3) / 4;           // ... in float4 records
     __shared__ __attribute__((aligned(16))) int smem[FWD_LDS_INTS];
@@ -685,30 +708,40 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_tile(blockIdx.x, T);
     const int tx = t % tiles_x, ty = row0 + t / tiles_x;
-    const int lx = ((wave & 1) << 3) + (lane & 7), ly = ((wave >> 1) << 3) + (lane >> 3);
-    const int j = tx * GI2D_BLOCK + lx, i = ty * GI2D_BLOCK + ly;
-    const bool inside = (i < H) && (j < W);
-    const float px = (float)j + cv.pixel_offset, py = (float)i + cv.pixel_offset;
+    // this wave's quadrants are wave*PPL .. wave*PPL+PPL-1; a lane is the same pixel of each
+    float px[PPL], py[PPL], r[PPL], g[PPL], b[PPL];
+    size_t pix[PPL];
+    bool inside[PPL];
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+        const int q = wave * PPL + u;
+        const int lx = ((q & 1) << 3) + (lane & 7), ly = ((q >> 1) << 3) + (lane >> 3);
+        const int j = tx * GI2D_BLOCK + lx, i = ty * GI2D_BLOCK + ly;
+        inside[u] = (i < H) && (j < W);
+        px[u] = (float)j + cv.pixel_offset;
+        py[u] = (float)i + cv.pixel_offset;
+        pix[u] = (size_t)(i - row0 * GI2D_BLOCK) * W + j;
+        r[u] = g[u] = b[u] = 0.f;
+    }
     int *lst = seg + (size_t)t * C;
     // the first batch's id is loaded before the list length is known (a segment always has C
     // words): one round trip to memory instead of two
     int gid_first = tid < C ? lst[tid] : 0;
     const int n_raw = FINALIZE ? tile_count[(size_t)t * CNT_STRIDE] : tile_len[t];
     const int n_all = min(n_raw, C);
-    float r = 0.f, g = 0.f, b = 0.f;
     float xacc[NX ? NX : 1];
 #pragma unroll
     for (int q = 0; q < NX; ++q) xacc[q] = 0.f;
     if (FINALIZE) {
         __syncthreads();  // every wave has read the counter before lane 0 returns it to zero
-        if (n_all > 256) {  // long list: sort it where it lies before the batches are read
+        if (n_all > BATCH) {  // long list: sort it where it lies before the batches are read
             if (n_all <= FWD_LDS_INTS) {
-                for (int k = tid; k < n_all; k += 256) smem[k] = lst[k];
+                for (int k = tid; k < n_all; k += BATCH) smem[k] = lst[k];
                 __syncthreads();
-                bitonic_sort(smem, n_all, tid, 256);
-                for (int k = tid; k < n_all; k += 256) lst[k] = smem[k];
+                bitonic_sort(smem, n_all, tid, BATCH);
+                for (int k = tid; k < n_all; k += BATCH) lst[k] = smem[k];
             } else {
-                bitonic_sort(lst, n_all, tid, 256);
+                bitonic_sort(lst, n_all, tid, BATCH);
             }
             __syncthreads();
         }
@@ -718,24 +751,24 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
     const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
     const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
     const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
-    for (int base = 0; base < n_all; base += 256) {
-        const int n = min(256, n_all - base);
+    for (int base = 0; base < n_all; base += BATCH) {
+        const int n = min(BATCH, n_all - base);
         __syncthreads();
         // (a long list was just re-sorted in place: the early copy of its first ids is stale)
-        const bool early = base == 0 && !(FINALIZE && n_all > 256);
+        const bool early = base == 0 && !(FINALIZE && n_all > BATCH);
         const int gid = tid < n ? (early ? gid_first : lst[base + tid]) : INT_MAX;
         int slot = tid;
-        if (FINALIZE && n_all <= 256) {
+        if (FINALIZE && n_all <= BATCH) {
             // rank of my id among the batch = its place in ascending order (ids are distinct)
             s_id[tid] = gid;
             __syncthreads();
-            int rank = 0;
-            for (int k = 0; k < n; k += 4) {
-                const int4 q = *reinterpret_cast<const int4 *>(s_id + k);
-                rank += (q.x < gid ? 1 : 0) + (q.y < gid ? 1 : 0) + (q.z < gid ? 1 : 0) +
-                        (q.w < gid ? 1 : 0);
-            }
-            if (tid < n) {
+            if (tid < n) {  // (waves wholly past the list skip the counting)
+                int rank = 0;
+                for (int k = 0; k < n; k += 4) {
+                    const int4 q = *reinterpret_cast<const int4 *>(s_id + k);
+                    rank += (q.x < gid ? 1 : 0) + (q.y < gid ? 1 : 0) + (q.z < gid ? 1 : 0) +
+                            (q.w < gid ? 1 : 0);
+                }
                 lst[rank] = gid;
                 slot = rank;
             }
@@ -769,85 +802,99 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
         s_m[slot] = mask;  // lanes past the batch keep slot = tid >= n and store 0
         __syncthreads();
         for (int c0 = 0; c0 < n; c0 += 64) {
-            unsigned long long bits = __ballot((s_m[c0 + lane] >> wave) & 1);
-            while (bits) {
-                const int k = c0 + (int)__builtin_ctzll(bits);
-                bits &= bits - 1;
-                const float4 A = s_a[k];
-                const float4 B = s_b[k];
-                const float cb = s_c[k];
-                const float dx = A.x - px, dy = A.y - py;
-                // p = -sigma*log2(e) = (A'dx + B'dy)dx + C'dy*dy
-                const float q = __builtin_fmaf(A.w, dy, A.z * dx);
-                const float p = __builtin_fmaf(B.x * dy, dy, q * dx);
-                const float e = __builtin_amdgcn_exp2f(p);
-                const float alpha = fminf(cv.alpha_cap, B.y * e);
-                const float w = (p > 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
-                r = __builtin_fmaf(B.z, w, r);
-                g = __builtin_fmaf(B.w, w, g);
-                b = __builtin_fmaf(cb, w, b);
-                if (NX) {
+            const int m = s_m[c0 + lane];
 #pragma unroll
-                    for (int q = 0; q < NX4; ++q) {
-                        const float4 X = s_x[q * 256 + k];
-                        const float xv[4] = {X.x, X.y, X.z, X.w};
+            for (int u = 0; u < PPL; ++u) {
+                unsigned long long bits = __ballot((m >> (wave * PPL + u)) & 1);
+                while (bits) {
+                    const int k = c0 + (int)__builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    const float4 A = s_a[k];
+                    const float4 B = s_b[k];
+                    const float cb = s_c[k];
+                    const float dx = A.x - px[u], dy = A.y - py[u];
+                    // p = -sigma*log2(e) = (A'dx + B'dy)dx + C'dy*dy
+                    const float q = __builtin_fmaf(A.w, dy, A.z * dx);
+                    const float p = __builtin_fmaf(B.x * dy, dy, q * dx);
+                    const float e = __builtin_amdgcn_exp2f(p);
+                    const float alpha = fminf(cv.alpha_cap, B.y * e);
+                    const float w = (p > 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
+                    r[u] = __builtin_fmaf(B.z, w, r[u]);
+                    g[u] = __builtin_fmaf(B.w, w, g[u]);
+                    b[u] = __builtin_fmaf(cb, w, b[u]);
+                    if (NX) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (4 * q + u < NX)
-                                xacc[4 * q + u] = __builtin_fmaf(xv[u], w, xacc[4 * q + u]);
+                        for (int q4 = 0; q4 < NX4; ++q4) {
+                            const float4 X = s_x[q4 * 256 + k];
+                            const float xv[4] = {X.x, X.y, X.z, X.w};
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (4 * q4 + v < NX)
+                                    xacc[4 * q4 + v] =
+                                        __builtin_fmaf(xv[v], w, xacc[4 * q4 + v]);
+                        }
                     }
                 }
             }
         }
     }
-    r = r + cv.bg_weight * bg0;
-    g = g + cv.bg_weight * bg1;
-    b = b + cv.bg_weight * bg2;
-    if (n_raw > C) r = g = b = __builtin_nanf("");  // overflowed segment: never silently wrong
-    const size_t pix = (size_t)(i - row0 * GI2D_BLOCK) * W + j;
-    if (inside && out != nullptr) {
-        float *o = out + 3 * pix;
-        o[0] = r;
-        o[1] = g;
-        o[2] = b;
+    float sq[PPL];
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+        float rr = r[u] + cv.bg_weight * bg0;
+        float gg = g[u] + cv.bg_weight * bg1;
+        float bb = b[u] + cv.bg_weight * bg2;
+        if (n_raw > C) rr = gg = bb = __builtin_nanf("");  // overflowed segment: never silently wrong
+        if (inside[u] && out != nullptr) {
+            float *o = out + 3 * pix[u];
+            o[0] = rr;
+            o[1] = gg;
+            o[2] = bb;
+        }
+        if (inside[u] && extra.out_chw != nullptr) {
+            float *o = extra.out_chw + pix[u];
+            // torch.clamp keeps a NaN (the overflow marker must survive); fmin/fmax would drop it
+            o[0] = rr != rr ? rr : fminf(fmaxf(rr, 0.f), 1.f);
+            o[extra.chw_plane] = gg != gg ? gg : fminf(fmaxf(gg, 0.f), 1.f);
+            o[2 * extra.chw_plane] = bb != bb ? bb : fminf(fmaxf(bb, 0.f), 1.f);
+        }
+        sq[u] = 0.f;
+        if (L2 && inside[u]) {
+            const size_t plane = (size_t)H * W;
+            const size_t gp = pix[u] + (size_t)(row0 * GI2D_BLOCK) * W;  // index in the full frame
+            const float scale = 2.0f / (3.0f * (float)plane);
+            const float v[3] = {rr, gg, bb};
+            float *vo = v_img + 3 * pix[u];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float x = v[ch];
+                const float d = fminf(fmaxf(x, 0.f), 1.f) - gt[ch * plane + gp];
+                sq[u] = __builtin_fmaf(d, d, sq[u]);
+                vo[ch] = (x >= 0.f && x <= 1.f) ? scale * d : 0.f;  // clamp passes its interior
+            }
+        }
     }
-    if (inside && extra.out_chw != nullptr) {
-        float *o = extra.out_chw + pix;
-        // torch.clamp keeps a NaN (the overflow marker must survive); fmin/fmax would drop it
-        o[0] = r != r ? r : fminf(fmaxf(r, 0.f), 1.f);
-        o[extra.chw_plane] = g != g ? g : fminf(fmaxf(g, 0.f), 1.f);
-        o[2 * extra.chw_plane] = b != b ? b : fminf(fmaxf(b, 0.f), 1.f);
-    }
-    if (NX && inside) {
+    if (NX && inside[0]) {
         const float bgs[3] = {bg0, bg1, bg2};
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
             float v = xacc[q] + cv.bg_weight * bgs[q % 3];
             if (n_raw > C) v = __builtin_nanf("");
-            extra.out[q / 3][3 * pix + q % 3] = v;
+            extra.out[q / 3][3 * pix[0] + q % 3] = v;
         }
     }
     if (L2) {
-        float sq = 0.f;
-        if (inside) {
-            const size_t plane = (size_t)H * W, gp = (size_t)i * W + j;
-            const float scale = 2.0f / (3.0f * (float)plane);
-            const float v[3] = {r, g, b};
-            float *vo = v_img + 3 * pix;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float x = v[ch];
-                const float d = fminf(fmaxf(x, 0.f), 1.f) - gt[ch * plane + gp];
-                sq = __builtin_fmaf(d, d, sq);
-                vo[ch] = (x >= 0.f && x <= 1.f) ? scale * d : 0.f;  // clamp passes its interior
-            }
-        }
-        // tile sum in a fixed order: lanes of a wave by DPP, the four waves through LDS
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) sq += __shfl_xor(sq, d);
+        // tile sum in a fixed order whatever the variant: the lanes of a quadrant by butterfly,
+        // the four quadrants through LDS
         __syncthreads();
         float *s_red = reinterpret_cast<float *>(smem);
-        if (lane == 0) s_red[wave] = sq;
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) {
+            float v = sq[u];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+            if (lane == 0) s_red[wave * PPL + u] = v;
+        }
         __syncthreads();
         if (tid == 0) loss_part[t] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     }
@@ -865,50 +912,41 @@ __global__ __launch_bounds__(256) void rasterize_sum_fwd_kernel(
 // SLOT_TAB tiles come from the table, the rest by binary search (lists ascend in Gaussian id).
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
-    const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
-    const float *__restrict__ xys, const int *__restrict__ radii,
-    const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
-    int T, gi2d_conv cv, int cull, const float *__restrict__ v_out,
-    float *__restrict__ partials, int *__restrict__ slot_tab)
+// sum over the LPE (4, 8 or 16) neighbouring lanes of an entry's group, result in every lane
+template <int LPE>
+__device__ __forceinline__ float group_sum(float v)
 {
-    __shared__ float4 s_v[256];
+    v = quad_sum(v);
+    if (LPE >= 8) v = v + dpp_mov<0x141>(v);   // row_half_mirror: lane i <-> 7-i of each 8
+    if (LPE >= 16) v = v + dpp_mov<0x140>(v);  // row_mirror: lane i <-> 15-i of each 16
+    return v;
+}
+
+// The batches of one tile with LPE lanes per list entry (256 / LPE entries per batch).
+template <int LPE>
+__device__ __forceinline__ void bwd_tile(
+    const int *__restrict__ lst, const int *s_first, int n_raw, size_t slot0, int tx, int ty,
+    const float4 *s_v, const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
+    const gi2d_conv &cv, int cull, float *__restrict__ partials, int *__restrict__ slot_tab)
+{
+    constexpr int EPB = 256 / LPE;  // entries per batch
     const int tid = threadIdx.x;
-    const int t = xcd_tile(blockIdx.x, T);
-    const int *lst = seg + (size_t)t * C;
-    // first batch's id before the length is known (a segment always has C >= 64 words)
-    const int gid_first = lst[tid >> 2];
-    const int n_raw = tile_len[t];
-    if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
-    const size_t slot0 = (size_t)t * C;
-    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
-    {
-        const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < H && j < W) {
-            const float *p = v_out + 3 * ((size_t)(i - row0 * GI2D_BLOCK) * W + j);
-            v.x = p[0];
-            v.y = p[1];
-            v.z = p[2];
-        }
-        s_v[tid] = v;
-    }
-    __syncthreads();
     const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
     const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
     const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
     const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
-    const int q = tid & 3;
-    for (int base = 0; base < n_raw; base += 64) {
-        const int e = base + (tid >> 2);
+    const int q = tid & (LPE - 1);
+    for (int base = 0; base < n_raw; base += EPB) {
+        const int e = base + tid / LPE;
         float acc[PART_STRIDE];
 #pragma unroll
         for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
         int gid = 0, rad = 0;
         float gx = 0.f, gy = 0.f;
         if (e < n_raw) {
-            gid = base == 0 ? gid_first : lst[e];
+            gid = base == 0 ? s_first[e] : lst[e];  // (the first 64 ids are already here)
             gx = xys[2 * gid];
             gy = xys[2 * gid + 1];
             rad = radii[gid];
@@ -919,17 +957,16 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
             if (cull) support_rect(gx, gy, a, b, c, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
             const int w = x1 - x0 + 1, h = y1 - y0 + 1;
             const int cnt = (w > 0 && h > 0) ? w * h : 0;
-            // the four lanes of the quad take the rectangle's pixels round-robin
-            // 4 / w for w in 1..16 without the integer-division sequence
-            const int step_y = cnt ? (w > 4 ? 0 : (w > 2 ? 1 : (w == 2 ? 2 : 4))) : 0;
-            const int step_x = cnt ? 4 - step_y * w : 0;
-            int x = x0 + q, y = y0;
-            while (cnt && x > x1) {
-                x -= w;
-                ++y;
-            }
+            // The lanes of the group take the rectangle's pixels round-robin.  LPE / w and
+            // q / w for w in 1..16 from the hardware reciprocal (exact here: the quotients'
+            // fractional parts are multiples of 1/w, well clear of the 1-ulp error).
+            const float rw = __builtin_amdgcn_rcpf((float)max(w, 1));
+            const int step_y = cnt ? (int)((float)LPE * rw + 1.0e-3f) : 0;
+            const int step_x = cnt ? LPE - step_y * w : 0;
+            const int qy = (int)(((float)q + 0.5f) * rw);
+            int x = x0 + q - qy * w, y = y0 + qy;
             const float pa = (-0.5f * LOG2E) * a, pb = (-LOG2E) * b, pc = (-0.5f * LOG2E) * c;
-            for (int k = q; k < cnt; k += 4) {
+            for (int k = q; k < cnt; k += LPE) {
                 const float dx = gx - (ox + (float)x), dy = gy - (oy + (float)y);
                 const float p = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
                 const float ex = __builtin_amdgcn_exp2f(p);
@@ -946,12 +983,13 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
                 const float va = live ? v_alpha : 0.f;
                 const float vs = -oe * va;
                 acc[8] = __builtin_fmaf(ex, va, acc[8]);
-                acc[0] = __builtin_fmaf(vs, __builtin_fmaf(b, dy, a * dx), acc[0]);
-                acc[1] = __builtin_fmaf(vs, __builtin_fmaf(c, dy, b * dx), acc[1]);
+                // moments of vs over the rectangle; the conic enters once, after the loop
                 const float hx = vs * dx, hy = vs * dy;
-                acc[2] = __builtin_fmaf(0.5f * hx, dx, acc[2]);
+                acc[0] += hx;
+                acc[1] += hy;
+                acc[2] = __builtin_fmaf(hx, dx, acc[2]);
                 acc[3] = __builtin_fmaf(hx, dy, acc[3]);
-                acc[4] = __builtin_fmaf(0.5f * hy, dy, acc[4]);
+                acc[4] = __builtin_fmaf(hy, dy, acc[4]);
                 x += step_x;
                 y += step_y;
                 if (x > x1) {
@@ -959,9 +997,15 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
                     ++y;
                 }
             }
+            // v_xy = sum vs * (conic . d) = conic . (sum vs * d); v_conic = (1/2, 1, 1/2) * moments
+            const float m0 = acc[0], m1 = acc[1];
+            acc[0] = __builtin_fmaf(b, m1, a * m0);
+            acc[1] = __builtin_fmaf(c, m1, b * m0);
+            acc[2] *= 0.5f;
+            acc[4] *= 0.5f;
         }
 #pragma unroll
-        for (int k = 0; k < PART_STRIDE; ++k) acc[k] = quad_sum(acc[k]);
+        for (int k = 0; k < PART_STRIDE; ++k) acc[k] = group_sum<LPE>(acc[k]);
         if (e < n_raw && q == 0) {
             float *dst = partials + (slot0 + e) * PART_STRIDE;
 #pragma unroll
@@ -976,6 +1020,47 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
+    const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
+    const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
+    int T, gi2d_conv cv, int cull, const float *__restrict__ v_out,
+    float *__restrict__ partials, int *__restrict__ slot_tab)
+{
+    __shared__ float4 s_v[256];
+    __shared__ int s_first[64];
+    const int tid = threadIdx.x;
+    const int t = xcd_tile(blockIdx.x, T);
+    const int *lst = seg + (size_t)t * C;
+    // the first 64 ids before the length is known (a segment always has C >= 64 words)
+    if (tid < 64) s_first[tid] = lst[tid];
+    const int n_raw = tile_len[t];
+    if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
+    const size_t slot0 = (size_t)t * C;
+    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
+    {
+        const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < H && j < W) {
+            const float *p = v_out + 3 * ((size_t)(i - row0 * GI2D_BLOCK) * W + j);
+            v.x = p[0];
+            v.y = p[1];
+            v.z = p[2];
+        }
+        s_v[tid] = v;
+    }
+    __syncthreads();
+    // a short list gets more lanes per entry: its rectangles are walked in fewer steps
+#define GI2D_BWD_TILE(LPE)                                                                      \
+    bwd_tile<LPE>(lst, s_first, n_raw, slot0, tx, ty, s_v, xys, radii, conics, colors, opacity, \
+                  H, W, tiles_x, tiles_y, row0, cv, cull, partials, slot_tab)
+    if (n_raw <= 16) GI2D_BWD_TILE(16);
+    else if (n_raw <= 32) GI2D_BWD_TILE(8);
+    else GI2D_BWD_TILE(4);
+#undef GI2D_BWD_TILE
 }
 
 // Adds up Gaussian g's slots of the partial-sum slab, in the row-major order of its tile box.
@@ -1275,6 +1360,7 @@ struct gi2d_workspace {
     bool prefilled = false;          // project_*_fwd filled the lists for the shape below
     int pre_n = 0, pre_tx = 0, pre_ty = 0, pre_r0 = 0, pre_r1 = 0;
     int cull = 1;
+    int raster_ppl = 0;  // 0 = choose by tile count
     int min_seg_cap = 64;
 };
 
@@ -1459,6 +1545,10 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
     if (!ws) return GI2D_E_INVALID;
     switch (option) {
         case GI2D_OPT_CULL: ws->cull = value ? 1 : 0; return GI2D_OK;
+        case GI2D_OPT_RASTER_PPL:
+            if (value != 0 && value != 1 && value != 2 && value != 4) return GI2D_E_INVALID;
+            ws->raster_ppl = value;
+            return GI2D_OK;
         default: return GI2D_E_INVALID;
     }
 }
@@ -1798,12 +1888,25 @@ int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_
     else if (ids && total > ids_capacity) rc = GI2D_E_CAPACITY;
     if (rc == GI2D_OK) {
         e = hipMemcpyAsync(tile_offsets, h_off, sizeof(int) * ((size_t)T + 1), hipMemcpyDefault, st);
-        // compaction: one copy per non-empty tile; a test / diagnostics path, not a hot one
-        for (int t = 0; t < T && e == hipSuccess && ids; ++t)
-            if (h_len[t] > 0)
-                e = hipMemcpyAsync(ids + h_off[t], ws->d_seg + (size_t)t * C,
-                                   sizeof(int) * (size_t)h_len[t], hipMemcpyDefault, st);
+        // compaction through a temporary on the device (the destinations may be host memory);
+        // a test / diagnostics path, not a hot one
+        int *d_off = nullptr, *d_ids = nullptr;
+        if (ids && total > 0 && e == hipSuccess) {
+            e = hipMalloc(&d_off, sizeof(int) * ((size_t)T + 1));
+            if (e == hipSuccess) e = hipMalloc(&d_ids, sizeof(int) * (size_t)total);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(d_off, h_off, sizeof(int) * ((size_t)T + 1),
+                                   hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) {
+                compact_lists_kernel<<<T, WAVE, 0, st>>>(ws->d_seg, C, ws->d_len, d_off, d_ids);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(ids, d_ids, sizeof(int) * (size_t)total, hipMemcpyDefault, st);
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (d_off) (void)hipFree(d_off);
+        if (d_ids) (void)hipFree(d_ids);
         if (e != hipSuccess) rc = (int)e;
     }
     free(h_len);
@@ -1859,16 +1962,36 @@ static int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *co
                          ws->cull, ws->d_status, ws->generation, out_img, gt, v_img, loss_part, \
                          extra
     const bool fin = ws->lists_raw;
+    // pixels per lane: many sparse tiles -> smaller workgroups, more tiles in flight per CU
+    int ppl = 1;
+    if (sets == 1) {
+        ppl = ws->raster_ppl;
+        if (ppl == 0) ppl = T >= GI2D_PPL4_MIN_TILES ? 4 : (T >= GI2D_PPL2_MIN_TILES ? 2 : 1);
+    }
+#define GI2D_RASTER_LAUNCH(FIN, LL, SETS, PPL) \
+    rasterize_sum_fwd_kernel<FIN, LL, SETS, PPL><<<T, 256 / PPL, 0, st>>>(GI2D_RASTER_ARGS)
+#define GI2D_RASTER_PICK(SETS, PPL)                         \
+    do {                                                    \
+        if (fin && l2) GI2D_RASTER_LAUNCH(true, true, SETS, PPL);   \
+        else if (fin) GI2D_RASTER_LAUNCH(true, false, SETS, PPL);   \
+        else if (l2) GI2D_RASTER_LAUNCH(false, true, SETS, PPL);    \
+        else GI2D_RASTER_LAUNCH(false, false, SETS, PPL);           \
+    } while (0)
     if (sets == 3) {
-        if (fin) rasterize_sum_fwd_kernel<true, false, 3><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
-        else rasterize_sum_fwd_kernel<false, false, 3><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+        if (fin) GI2D_RASTER_LAUNCH(true, false, 3, 1);
+        else GI2D_RASTER_LAUNCH(false, false, 3, 1);
     } else if (sets == 2) {
-        if (fin) rasterize_sum_fwd_kernel<true, false, 2><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
-        else rasterize_sum_fwd_kernel<false, false, 2><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
-    } else if (fin && l2) rasterize_sum_fwd_kernel<true, true, 1><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
-    else if (fin) rasterize_sum_fwd_kernel<true, false, 1><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
-    else if (l2) rasterize_sum_fwd_kernel<false, true, 1><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
-    else rasterize_sum_fwd_kernel<false, false, 1><<<T, 256, 0, st>>>(GI2D_RASTER_ARGS);
+        if (fin) GI2D_RASTER_LAUNCH(true, false, 2, 1);
+        else GI2D_RASTER_LAUNCH(false, false, 2, 1);
+    } else if (ppl == 4) {
+        GI2D_RASTER_PICK(1, 4);
+    } else if (ppl == 2) {
+        GI2D_RASTER_PICK(1, 2);
+    } else {
+        GI2D_RASTER_PICK(1, 1);
+    }
+#undef GI2D_RASTER_PICK
+#undef GI2D_RASTER_LAUNCH
 #undef GI2D_RASTER_ARGS
     if (fin) {
         ws->lists_raw = false;

@@ -96,6 +96,11 @@ class Workspace:
         check(lib.gi2d_workspace_set_option(self.handle, _lib.OPT_CULL, int(bool(on))),
               "gi2d_workspace_set_option")
 
+    def set_raster_ppl(self, ppl):
+        """Pixels per lane of the forward rasteriser (1, 2, 4; 0 = automatic)."""
+        check(lib.gi2d_workspace_set_option(self.handle, _lib.OPT_RASTER_PPL, int(ppl)),
+              "gi2d_workspace_set_option")
+
     # -- binning ---------------------------------------------------------------------------
     @staticmethod
     def _key(xys, radii, H, W):
@@ -125,13 +130,20 @@ class Workspace:
         check(lib.gi2d_workspace_reserve(self.handle, int(per_tile_capacity), int(max_tiles)),
               "gi2d_workspace_reserve")
 
-    def bins(self):
-        """(tile_offsets, ids) of the current lists as CPU int32 tensors (synchronises)."""
+    def offsets(self):
+        """Exclusive scan of the current list lengths, ``tiles + 1`` ints on the device
+        (synchronises); the last entry is the number of intersections."""
         inf = self.info()
         T = inf["tiles_x"] * (inf["row_end"] - inf["row_begin"])
-        st = _stream(self.device)
         offs = torch.empty(T + 1, dtype=torch.int32, device=self.device)
-        check(lib.gi2d_copy_bins(self.handle, _ptr(offs), None, 0, st), "gi2d_copy_bins")
+        check(lib.gi2d_copy_bins(self.handle, _ptr(offs), None, 0, _stream(self.device)),
+              "gi2d_copy_bins")
+        return offs
+
+    def bins(self):
+        """(tile_offsets, ids) of the current lists as CPU int32 tensors (synchronises)."""
+        st = _stream(self.device)
+        offs = self.offsets()
         total = int(offs[-1].item())
         ids = torch.empty(max(total, 1), dtype=torch.int32, device=self.device)
         check(lib.gi2d_copy_bins(self.handle, _ptr(offs), _ptr(ids), ids.numel(), st),

@@ -202,4 +202,4 @@ class FramePipeline:
 
     def intersections(self):
         """Number of (tile, Gaussian) intersections of the last binning (synchronises)."""
-        return int(self.ws.bins()[0][-1])
+        return int(self.ws.offsets()[-1].item())

@@ -68,6 +68,10 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
  * Gaussian's support rectangle; 0 evaluates every pixel of every listed tile
  * (same results, used by the tests to prove that). */
 #define GI2D_OPT_CULL 1
+/* GI2D_OPT_RASTER_PPL: pixels per lane of the forward rasteriser: 1, 2 or 4
+ * (workgroups of 4, 2 or 1 waves per tile), 0 (default) = chosen from the tile
+ * count.  A tuning knob: every setting gives the same bits. */
+#define GI2D_OPT_RASTER_PPL 2
 int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value);
 /* Tile-row band: binning and rasterisation cover tile rows [row_begin,row_end)
  * of the frame only (row_end is clipped to the frame); out_img / v_out then

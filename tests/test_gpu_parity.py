@@ -566,3 +566,82 @@ def test_harness_fused_passes_equal_the_three_pass_forward(ops, oracle):
     assert set(oa) == set(ob) == {"render", "gauss_render", "alpha_map"}
     for k in oa:
         assert torch.equal(oa[k], ob[k]), k
+
+
+@pytest.mark.parametrize("H,W,N,seed,fp", [(80, 96, 512, 1, 1.0), (33, 50, 300, 2, 2.0),
+                                           (64, 64, 3000, 5, 6.0), (48, 48, 9000, 11, 8.0)])
+def test_pixels_per_lane_variants_give_the_same_bits(ops, oracle, H, W, N, seed, fp):
+    """The forward rasteriser's workgroup shapes (4, 2, 1 waves per tile) are interchangeable:
+    same image bits as the sorting first pass and as a later pass, same finalised lists --
+    including lists longer than one batch of the small workgroups (64 / 128 entries) and longer
+    than the LDS sort buffer."""
+    from gaussianimage_amd.pipeline import FramePipeline
+    means, L, col, op = (t.to(DEV) for t in synth.cholesky_inputs(N, seed=seed, footprint=fp))
+    op = (0.2 + 0.8 * torch.rand(N, 1, generator=torch.Generator().manual_seed(seed))).to(DEV)
+    pipe = FramePipeline(N, H, W, device=DEV, workspace=ops.Workspace(DEV))
+    results = {}
+    for ppl in (1, 2, 4):
+        pipe.ws.set_raster_ppl(ppl)
+        first = pipe.forward(means, L, None, col, op).clone()
+        offs, ids = pipe.ws.bins()
+        later = pipe.rasterize(col, op).clone()
+        results[ppl] = (first, later, offs.clone(), ids.clone())
+    pipe.ws.set_raster_ppl(0)
+    base = results[1]
+    assert torch.equal(base[0], base[1])
+    lens = np.diff(base[2].numpy())
+    if N >= 3000:
+        assert lens.max() > 256  # the long-list paths are exercised
+    for ppl in (2, 4):
+        for a, b in zip(results[ppl], base):
+            assert torch.equal(a, b), ppl
+    with pytest.raises(Exception):
+        pipe.ws.set_raster_ppl(3)
+
+
+@pytest.mark.parametrize("kind", ["cholesky", "rs"])
+def test_fit_forward_is_the_same_for_every_pixels_per_lane(ops, oracle, kind):
+    """Loss epilogue variant: image gradient, per-tile loss partials and rendered image do not
+    depend on the workgroup shape."""
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N = 96, 112, 1500
+    gt = synth.target_image(H, W).to(DEV)
+    got = {}
+    for ppl in (1, 2, 4):
+        torch.manual_seed(5)
+        fit = FusedFitter(N, H, W, kind=kind, device=DEV, keep_image=True)
+        fit.ws.set_raster_ppl(ppl)
+        fit.forward(gt)
+        got[ppl] = (fit.v_image.clone(), fit.loss_partials.clone(), fit.image.clone())
+    for ppl in (2, 4):
+        for a, b in zip(got[ppl], got[1]):
+            assert torch.equal(a, b), ppl
+
+
+def test_masked_opacities_and_their_gradient(ops, oracle):
+    """The pruning variant of the model multiplies the opacities by a (partly zero) mask that
+    needs a gradient (gaussianimage_cholesky_wMask.py:221-226): zero-opacity Gaussians
+    contribute nothing, and v_opacity is right for every Gaussian, masked ones included."""
+    H, W, N = 80, 96, 700
+    means, L, col, op, proj, ws = _project_and_bin(ops, oracle, H, W, N, 9, 2.0)
+    g = torch.Generator().manual_seed(9)
+    mask = (torch.rand(N, 1, generator=g) > 0.4).float()
+    soft = torch.rand(N, 1, generator=g)
+    opac = torch.where(torch.rand(N, 1, generator=g) > 0.5, mask, mask * soft)
+    xys, depths, radii, conics, nth = proj
+    o = opac.to(DEV).requires_grad_(True)
+    c = col.to(DEV).requires_grad_(True)
+    img = ops.rasterize_gaussians_sum(xys, depths, radii, conics, nth, c, o, H, W, 16, 16)
+    v_out = torch.randn(H, W, 3, generator=g)
+    (img * v_out.to(DEV)).sum().backward()
+    offs, ids = oracle.bin_tiles(_np(xys), _np(radii), H, W)
+    ref, margin = oracle.rasterize_sum_fwd(_np(xys), _np(conics), col.numpy(), opac.numpy(), H, W,
+                                           offs, ids, want_margin=True)
+    ok = margin > 1e-4
+    assert np.abs(_np(img) - ref)[ok].max() <= IMG_ATOL
+    r = oracle.rasterize_sum_bwd(_np(xys), _np(conics), col.numpy(), opac.numpy(), H, W, offs, ids,
+                                 v_out.numpy())
+    assert _maxrel(_np(c.grad), r[2]) <= GRAD_RTOL
+    assert _maxrel(_np(o.grad), r[3].reshape(N, 1)) <= GRAD_RTOL
+    dead = (opac == 0).reshape(-1).numpy()
+    assert dead.sum() > 100 and not _np(c.grad)[dead].any()
