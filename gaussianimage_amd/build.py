@@ -1,40 +1,64 @@
-"""Builds the native library in-tree: ``gaussianimage_amd/csrc/libgi2d.so`` for gfx950."""
+"""Builds the native library in-tree: ``gaussianimage_amd/csrc/libgi2d.so`` for gfx950.
+
+One hipcc compile per translation unit (in parallel), one link.  Objects go to
+``csrc/_build`` (ignored by git); only the ``.so`` is loaded at run time."""
+import glob
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["gi2d.hip"]
+SOURCES = ["lists.hip", "project.hip", "raster_fwd.hip", "raster_bwd.hip", "fit.hip"]
 LIB = os.path.join(CSRC, "libgi2d.so")
+OBJ_DIR = os.path.join(CSRC, "_build")
 
 # -ffp-contract=off: the projection's integer outputs must not depend on fused multiply-adds
-#  chosen by the compiler; -packed-fp32-ops off: keep hipcc from forming v_pk_*_f32.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+#  chosen by the compiler; -packed-fp32-ops off: keep hipcc from forming v_pk_*_f32;
+#  hidden visibility on the host side: the library exports its C ABI and nothing else.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-ffp-contract=off", "-fno-fast-math",
-               "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+               "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
+               "-Xarch_host", "-fvisibility=hidden"]
 
 
 def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+def _deps():
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + glob.glob(os.path.join(CSRC, "*.h"))
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "gi2d.h"))
+    return deps
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES]
-    deps.append(os.path.join(os.path.dirname(_HERE), "include", "gi2d.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build_native(force=False, extra_flags=(), verbose=False):
+def build_native(force=False, extra_flags=(), verbose=False, jobs=None):
     if not force and not stale():
         return LIB
-    cmd = [hipcc(), *HIPCC_FLAGS, *extra_flags, "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = []
+    cmds = []
+    for s in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        cmds.append([hipcc(), *HIPCC_FLAGS, *extra_flags, "-c", os.path.join(CSRC, s), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(cmds), os.cpu_count() or 1, 8)) as pool:
+        list(pool.map(run, cmds))
+    run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     return LIB
 
 

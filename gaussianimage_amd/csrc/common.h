@@ -1,0 +1,106 @@
+// common.h -- constants and small device helpers shared by every translation unit of libgi2d.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <new>
+
+// the library is built with hidden visibility; the C ABI is what it exports
+#pragma GCC visibility push(default)
+#include "../../include/gi2d.h"
+#pragma GCC visibility pop
+
+#define WAVE 64
+// Workgroup size of the per-Gaussian kernels that issue scattered atomics: one wave, so that
+// the launch spreads over every CU.
+#define PG_THREADS 64
+// Per-tile counters live one per 128-byte line: device-scope atomics on one line serialise at
+// the memory side, and ~48 Gaussians per tile hammering 32 neighbouring counters of one line
+// made the atomic pass three times slower.
+#define CNT_STRIDE 32
+#define LOG2E 1.4426950408889634f
+#define PART_STRIDE 9  // backward partial sums per (tile, Gaussian): v_xy 2, v_conic 3, v_rgb 3, v_op 1
+#define SLOT_TAB 4     // slots per Gaussian remembered by backward pass 1 (boxes are mostly <= 2x2)
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+
+// device-side status of a workspace
+struct DevStatus {
+    int max_count;            // largest per-tile count seen so far (monotone; capacity policy)
+    int pad;
+    long long overflow_gen;   // generation of the last frame in which a segment overflowed
+};
+
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (!(v == v)) return 0;
+    v = fminf(fmaxf(v, -2147483520.0f), 2147483520.0f);
+    return (int)v;
+}
+
+// Conic (inverse covariance) and integer 3-sigma radius; false = early-out.
+__device__ __forceinline__ bool cov_to_conic_radius(float sxx, float sxy, float syy, float &ca,
+                                                    float &cb, float &cc, float &radius)
+{
+    float det = sxx * syy - sxy * sxy;
+    if (det == 0.0f || !(fabsf(det) <= 3.0e38f)) return false;
+    float inv_det = 1.0f / det;
+    ca = syy * inv_det;
+    cb = -sxy * inv_det;
+    cc = sxx * inv_det;
+    float b = 0.5f * (sxx + syy);
+    float disc = fmaxf(0.1f, b * b - det);
+    float s = sqrtf(disc);
+    float v1 = b + s;
+    float v2 = b - s;
+    float r = ceilf(3.0f * sqrtf(fmaxf(v1, v2)));
+    if (!(r <= 3.0e38f)) return false;
+    radius = r;
+    return true;
+}
+
+struct TileBox {
+    int x0, x1, y0, y1;  // [x0,x1) x [y0,y1)
+};
+
+__device__ __forceinline__ TileBox tile_box(float cx, float cy, float radius, int tiles_x,
+                                            int tiles_y)
+{
+    float tcx = cx / (float)GI2D_BLOCK, tcy = cy / (float)GI2D_BLOCK;
+    float tr = radius / (float)GI2D_BLOCK;
+    TileBox b;
+    b.x0 = min(max(0, f2i_sat(tcx - tr)), tiles_x);
+    b.x1 = min(max(0, f2i_sat(tcx + tr + 1.0f)), tiles_x);
+    b.y0 = min(max(0, f2i_sat(tcy - tr)), tiles_y);
+    b.y1 = min(max(0, f2i_sat(tcy + tr + 1.0f)), tiles_y);
+    return b;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over the 4 lanes of a quad, result in every lane of the quad
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v = v + dpp_mov<0xB1>(v);  // quad_perm:[1,0,3,2]
+    v = v + dpp_mov<0x4E>(v);  // quad_perm:[2,3,0,1]
+    return v;
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share one).  This maps the
+// launch index to a tile index so that each XCD works on a contiguous run of tiles: neighbouring
+// tiles share Gaussians (L2 hits on the gathers) and image cache lines.  Bijective for any T.
+__device__ __forceinline__ int xcd_tile(int bid, int T)
+{
+    const int q = T >> 3, r = T & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}

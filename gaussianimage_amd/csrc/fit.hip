@@ -1,0 +1,251 @@
+// fit.hip -- the Adan step over all parameter tensors in one launch, and the fused fitting
+// iteration (forward with loss epilogue; backward rasterisation + gather + projection backward +
+// activation backward + Adan in place).
+#include "adan.h"
+#include "gather.h"
+#include "host.h"
+#include "projection.h"
+
+// ------------------------------------------------------------------------------------------
+// Adan step, fused: one launch over all parameter tensors, one read and one write of each of
+// p, m, n, diff, neg_pre_grad (the reference's default path makes 18 multi-tensor passes).
+// Operation order per element follows /root/reference/optimizer.py:319-362.
+// ------------------------------------------------------------------------------------------
+
+template <bool RS>
+__global__ __launch_bounds__(256) void fit_tail_kernel(
+    AdanTensors T, AdanScalars h, const float *__restrict__ xys, const int *__restrict__ radii,
+    int N, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
+    const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
+    const float *__restrict__ partials, const int *__restrict__ slot_tab)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    // Parameters and optimizer state first: these loads do not depend on the gather below, so
+    // they are in flight while its three dependent rounds (table, lengths, partials) complete.
+    const size_t g2 = 2 * (size_t)g, g3 = 3 * (size_t)g;
+    const AdanSlot x0 = adan_load(T, 0, g2), x1 = adan_load(T, 0, g2 + 1);
+    const AdanSlot c0 = adan_load(T, 1, RS ? g2 : g3), c1 = adan_load(T, 1, (RS ? g2 : g3) + 1);
+    const AdanSlot c2 = adan_load(T, RS ? 2 : 1, RS ? (size_t)g : g3 + 2);
+    const AdanSlot f0 = adan_load(T, 3, g3), f1 = adan_load(T, 3, g3 + 1),
+                   f2 = adan_load(T, 3, g3 + 2);
+    float acc[PART_STRIDE];
+    gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
+                    tile_len, seg, C, partials, slot_tab, acc);
+    const float t0 = tanhf(x0.p), t1 = tanhf(x1.p);
+    // means = tanh(_xyz); xys = 0.5*(W,H)*means + ...
+    const float gx0 = 0.5f * (float)W * acc[0] * (1.0f - t0 * t0);
+    const float gx1 = 0.5f * (float)H * acc[1] * (1.0f - t1 * t1);
+    float a, b, c, radius;
+    float vm0 = 0.f, vm1 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (!RS) {
+        const float l11 = c0.p + 0.5f, l21 = c1.p, l22 = c2.p + 0.5f;
+        if (cov_to_conic_radius(l11 * l11, l11 * l21, l21 * l21 + l22 * l22, a, b, c, radius)) {
+            float gxx, gxy, gyy;
+            conic_grad_to_cov_grad(a, b, c, acc[2], acc[3], acc[4], gxx, gxy, gyy);
+            o0 = 2.0f * l11 * gxx + l21 * gxy;
+            o1 = l11 * gxy + 2.0f * l21 * gyy;
+            o2 = 2.0f * l22 * gyy;
+            vm0 = gx0;
+            vm1 = gx1;
+        }
+    } else {
+        const float u1 = c0.p + 0.5f, u2 = c1.p + 0.5f;
+        const float s1 = fabsf(u1), s2 = fabsf(u2);
+        const float sg = 1.0f / (1.0f + expf(-c2.p));
+        const float theta = sg * 2.0f * 3.14159274f;
+        float sn, cs;
+        sincosf(theta, &sn, &cs);
+        const float q1 = s1 * s1, q2 = s2 * s2;
+        if (cov_to_conic_radius(cs * cs * q1 + sn * sn * q2, cs * sn * (q1 - q2),
+                                sn * sn * q1 + cs * cs * q2, a, b, c, radius)) {
+            float gxx, gxy, gyy;
+            conic_grad_to_cov_grad(a, b, c, acc[2], acc[3], acc[4], gxx, gxy, gyy);
+            const float gq1 = gxx * cs * cs + gxy * cs * sn + gyy * sn * sn;
+            const float gq2 = gxx * sn * sn - gxy * cs * sn + gyy * cs * cs;
+            // d|u|/du = sign(u) (0 at 0, like torch.abs)
+            o0 = 2.0f * s1 * gq1 * (u1 > 0.f ? 1.f : (u1 < 0.f ? -1.f : 0.f));
+            o1 = 2.0f * s2 * gq2 * (u2 > 0.f ? 1.f : (u2 < 0.f ? -1.f : 0.f));
+            const float dq = q1 - q2;
+            const float vtheta = dq * (-2.0f * cs * sn * gxx + (cs * cs - sn * sn) * gxy +
+                                       2.0f * cs * sn * gyy);
+            o2 = vtheta * 2.0f * 3.14159274f * sg * (1.0f - sg);
+            vm0 = gx0;
+            vm1 = gx1;
+        }
+    }
+    adan_apply(h, T, 0, g2, x0, vm0);
+    adan_apply(h, T, 0, g2 + 1, x1, vm1);
+    adan_apply(h, T, 1, RS ? g2 : g3, c0, o0);
+    adan_apply(h, T, 1, (RS ? g2 : g3) + 1, c1, o1);
+    adan_apply(h, T, RS ? 2 : 1, RS ? (size_t)g : g3 + 2, c2, o2);
+    adan_apply(h, T, 3, g3, f0, acc[5]);
+    adan_apply(h, T, 3, g3 + 1, f1, acc[6]);
+    adan_apply(h, T, 3, g3 + 2, f2, acc[7]);
+}
+
+__global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScalars h,
+                                                        const float *__restrict__ clip_dev)
+{
+    const int k = blockIdx.y;
+    float *__restrict__ p = T.p[k];
+    float *__restrict__ gr = T.g[k];
+    float *__restrict__ m = T.m[k];
+    float *__restrict__ n = T.n[k];
+    float *__restrict__ d = T.d[k];
+    float *__restrict__ prev = T.prev[k];
+    const long long numel = T.numel[k];
+    const float clip = clip_dev ? clip_dev[0] : 1.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel;
+         i += (long long)gridDim.x * blockDim.x) {
+        float g = gr[i];
+        if (clip_dev) {
+            g = g * clip;
+            gr[i] = g;  // the reference scales the gradient in place
+        }
+        adan_inplace(h, g, p, m, n, d, prev, (size_t)i);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+static int adan_scalars(const gi2d_adan_hyper *hyper, AdanScalars &h)
+{
+    if (!hyper || hyper->step < 1) return GI2D_E_INVALID;
+    const double b1 = hyper->beta1, b2 = hyper->beta2, b3 = hyper->beta3, lr = hyper->lr;
+    const double bc1 = 1.0 - pow(b1, (double)hyper->step);
+    const double bc2 = 1.0 - pow(b2, (double)hyper->step);
+    const double bc3 = 1.0 - pow(b3, (double)hyper->step);
+    h.beta1 = (float)b1;
+    h.omb1 = (float)(1.0 - b1);
+    h.beta2 = (float)b2;
+    h.omb2 = (float)(1.0 - b2);
+    h.beta3 = (float)b3;
+    h.omb3 = (float)(1.0 - b3);
+    h.bc3_sqrt = (float)sqrt(bc3);
+    h.eps = (float)hyper->eps;
+    h.neg_step = (float)(-(lr / bc1));
+    h.neg_step_diff = (float)(-(lr * b2 / bc2));
+    h.decay_mul = (float)(1.0 - lr * hyper->weight_decay);
+    h.decay_div = (float)(1.0 + lr * hyper->weight_decay);
+    h.no_prox = hyper->no_prox ? 1 : 0;
+    h.first_step = hyper->step == 1 ? 1 : 0;
+    return GI2D_OK;
+}
+
+
+extern "C" {
+
+int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
+                     const float *cov_b, const float *features, const float *opacity,
+                     const float *gt_chw, int N, int H, int W, const gi2d_conv *conv, float *xys,
+                     float *depths, int *radii, float *conics, int *num_tiles_hit, float *image,
+                     float *v_image, float *loss_partials, void *stream)
+{
+    if (!ws || (kind != 0 && kind != 1) || !gt_chw) return GI2D_E_INVALID;
+    const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
+    int rc = project_impl(kind, true, xyz, cov_a, cov_b, N, H, W, tiles_x, tiles_y, conv, xys,
+                          depths, radii, conics, num_tiles_hit, ws, stream);
+    if (rc != GI2D_OK) return rc;
+    rc = gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
+    if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
+    const int late = rc;
+    rc = raster_fwd_impl(ws, xys, conics, features, opacity, nullptr, N, H, W, conv, image, gt_chw,
+                         v_image, loss_partials, stream);
+    return rc != GI2D_OK ? rc : late;
+}
+
+int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                           float *features, const float *opacity, int N, int H, int W,
+                           const gi2d_conv *conv, const float *xys, const int *radii,
+                           const float *conics, const float *v_image, float *const *exp_avg,
+                           float *const *exp_avg_sq, float *const *exp_avg_diff,
+                           float *const *neg_pre_grad, const gi2d_adan_hyper *hyper, void *stream)
+{
+    if (kind != 0 && kind != 1) return GI2D_E_INVALID;
+    int rc = check_raster_args(ws, N, H, W, conv);
+    if (rc != GI2D_OK) return rc;
+    AdanScalars h;
+    rc = adan_scalars(hyper, h);
+    if (rc != GI2D_OK) return rc;
+    if (N == 0) return GI2D_OK;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (!xyz || !cov_a || (kind == 1 && !cov_b) || !features || !opacity || !xys || !radii ||
+        !conics || (!v_image && T > 0) || !exp_avg || !exp_avg_sq || !exp_avg_diff ||
+        !neg_pre_grad)
+        return GI2D_E_INVALID;
+    AdanTensors Tn;
+    float *ps[4] = {xyz, cov_a, kind == 1 ? cov_b : xyz, features};
+    for (int k = 0; k < ADAN_MAX_TENSORS; ++k) {
+        const int src = k < 4 ? k : 0;
+        if (k < 4 && (k != 2 || kind == 1) &&
+            (!exp_avg[src] || !exp_avg_sq[src] || !exp_avg_diff[src] || !neg_pre_grad[src]))
+            return GI2D_E_INVALID;
+        Tn.p[k] = ps[src];
+        Tn.g[k] = nullptr;
+        Tn.m[k] = exp_avg[src];
+        Tn.n[k] = exp_avg_sq[src];
+        Tn.d[k] = exp_avg_diff[src];
+        Tn.prev[k] = neg_pre_grad[src];
+        Tn.numel[k] = 0;
+    }
+    DeviceGuard guard(ws->device);
+    hipStream_t st = (hipStream_t)stream;
+    rc = raster_bwd_pass1(ws, xys, radii, conics, features, opacity, N, H, W, conv, v_image, st);
+    if (rc != GI2D_OK) return rc;
+    if (kind == 0)
+        fit_tail_kernel<false><<<cdiv(N, 256), 256, 0, st>>>(
+            Tn, h, xys, radii, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1,
+            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_slot_tab);
+    else
+        fit_tail_kernel<true><<<cdiv(N, 256), 256, 0, st>>>(
+            Tn, h, xys, radii, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1,
+            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_slot_tab);
+    return launch_status();
+}
+
+int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
+                   float *const *exp_avg, float *const *exp_avg_sq, float *const *exp_avg_diff,
+                   float *const *neg_pre_grad, const int64_t *numel, const gi2d_adan_hyper *hyper,
+                   const float *clip_dev, void *stream)
+{
+    if (num_tensors < 0) return GI2D_E_INVALID;
+    AdanScalars h;
+    int rcs = adan_scalars(hyper, h);
+    if (rcs != GI2D_OK) return rcs;
+    if (num_tensors == 0) return GI2D_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !exp_avg_diff || !neg_pre_grad || !numel)
+        return GI2D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < num_tensors; base += ADAN_MAX_TENSORS) {
+        AdanTensors T;
+        const int cnt = num_tensors - base < ADAN_MAX_TENSORS ? num_tensors - base : ADAN_MAX_TENSORS;
+        long long longest = 0;
+        for (int k = 0; k < ADAN_MAX_TENSORS; ++k) {
+            const int src = base + (k < cnt ? k : 0);
+            if (numel[src] < 0) return GI2D_E_INVALID;
+            if (numel[src] > 0 && (!params[src] || !grads[src] || !exp_avg[src] ||
+                                   !exp_avg_sq[src] || !exp_avg_diff[src] || !neg_pre_grad[src]))
+                return GI2D_E_INVALID;
+            T.p[k] = params[src];
+            T.g[k] = grads[src];
+            T.m[k] = exp_avg[src];
+            T.n[k] = exp_avg_sq[src];
+            T.d[k] = exp_avg_diff[src];
+            T.prev[k] = neg_pre_grad[src];
+            T.numel[k] = k < cnt ? (long long)numel[src] : 0;
+            if (T.numel[k] > longest) longest = T.numel[k];
+        }
+        if (longest == 0) continue;
+        long long blocks = (longest + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        adan_step_kernel<<<dim3((unsigned)blocks, (unsigned)cnt), 256, 0, st>>>(T, h, clip_dev);
+        int rc = launch_status();
+        if (rc != GI2D_OK) return rc;
+    }
+    return GI2D_OK;
+}
+
+}  // extern "C"

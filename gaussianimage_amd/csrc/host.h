@@ -1,0 +1,101 @@
+// host.h -- host-side state of a workspace and the internal entry points the translation
+// units of libgi2d share (none of them is exported).
+#pragma once
+#include "common.h"
+
+struct gi2d_workspace {
+    int device = 0;
+    int tiles_cap = 0;          // tiles the per-tile arrays are allocated for
+    int seg_cap = 0;            // C: ids per tile segment
+    int *d_count = nullptr;     // [tiles_cap][CNT_STRIDE] per-tile counters, zero between frames
+    int *d_len = nullptr;       // [tiles_cap] list length of the finalised lists
+    int *d_seg = nullptr;       // [tiles_cap][seg_cap] Gaussian ids per tile
+    int64_t part_slots = 0;
+    float *d_partials = nullptr;  // [tiles][seg_cap][9] backward partial sums
+    int64_t slot_cap = 0;
+    int *d_slot_tab = nullptr;  // [n][SLOT_TAB] list position of a Gaussian in its first tiles
+    DevStatus *d_status = nullptr;
+    long long *h_status = nullptr;  // pinned: [0] max count, [1] generation, [2] overflow gen.
+    long long *h_status_dev = nullptr;
+    int64_t generation = 0;
+    int64_t overflow_ack = 0;
+    int tiles_x = 0, tiles_y = 0, n_binned = 0;
+    int row0 = 0, row1 = INT_MAX;    // tile rows requested by the caller (a band)
+    int bin_row0 = 0, bin_row1 = 0;  // tile rows of the current lists
+    bool counters_dirty = false;     // counters may be non-zero
+    bool lists_raw = false;          // lists filled but not yet sorted / finalised
+    bool lists_valid = false;        // lists belong to the binning that (tiles_x, ...) describe
+    bool prefilled = false;          // project_*_fwd filled the lists for the shape below
+    int pre_n = 0, pre_tx = 0, pre_ty = 0, pre_r0 = 0, pre_r1 = 0;
+    int cull = 1;
+    int raster_ppl = 0;  // 0 = choose by tile count
+    int min_seg_cap = 64;
+};
+
+#define HIP_TRY(expr)                                \
+    do {                                             \
+        hipError_t err__ = (expr);                   \
+        if (err__ != hipSuccess) return (int)err__;  \
+    } while (0)
+
+static inline int launch_status()
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GI2D_OK : (int)e;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
+
+namespace {
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (dev < 0) return;  // nothing to guard
+        if (hipGetDevice(&prev) != hipSuccess) ok = false;
+        if (ok && prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+
+// Further colour sets and the optional planar output of the forward rasteriser.
+struct ExtraSets {
+    const float *colors[2];  // [N,3] each
+    float *out[2];           // [H,W,3] each
+    // optional second form of the first image: clamped to [0,1] and planar, [3][rows][W] -- the
+    // model's "render" tensor (gaussianimage_cholesky.py:83-84) without the torch ops behind it
+    float *out_chw;
+    size_t chw_plane;        // rows * W of the band being rendered
+};
+
+// lists.hip
+int ensure_lists(gi2d_workspace *ws, int T, int C);
+int wanted_cap(const gi2d_workspace *ws, long long seen);
+int zero_counters(gi2d_workspace *ws, hipStream_t st);
+int finalize_lists(gi2d_workspace *ws, hipStream_t st);
+int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream_t st);
+
+// project.hip
+int project_impl(int kind, bool raw, const float *means, const float *cov_a, const float *cov_b,
+                 int N, int H, int W, int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
+                 float *depths, int *radii, float *conics, int *num_tiles_hit, gi2d_workspace *ws,
+                 void *stream, const gi2d_codec *codec = nullptr, float *colors_out = nullptr);
+
+// raster_fwd.hip
+int check_raster_args(gi2d_workspace *ws, int N, int H, int W, const gi2d_conv *conv);
+int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *conics, const float *colors,
+                    const float *opacity, const float *background, int N, int H, int W,
+                    const gi2d_conv *conv, float *out_img, const float *gt, float *v_img,
+                    float *loss_part, void *stream, int sets = 1, ExtraSets extra = ExtraSets());
+
+// raster_bwd.hip
+int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii, const float *conics,
+                     const float *colors, const float *opacity, int N, int H, int W,
+                     const gi2d_conv *conv, const float *v_out, hipStream_t st);

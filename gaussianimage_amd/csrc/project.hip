@@ -1,0 +1,411 @@
+// libgi2d -- MI355X (gfx950, wave64) kernels and C ABI of the accumulated-summation 2D Gaussian
+// rasterizer.  This file: projection (Cholesky / rotation-scale / coded attributes), forward and
+// backward.  lists.hip: workspace and binning; raster_fwd.hip / raster_bwd.hip: rasterize_sum;
+// fit.hip: Adan and the fused fitting step.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off, one object per .hip file, linked
+// into one shared library (see build.py).
+// -ffp-contract=off is part of the contract: the projection's integer outputs (radii, tile
+// boxes) must not depend on the compiler's choice of fused multiply-adds.  Where a fused
+// multiply-add is wanted in a hot loop it is written explicitly with __builtin_fmaf.
+//
+// Frame pipeline (forward): TWO launches in steady state.
+//   1. project_*_fwd_kernel  -- per Gaussian: conic, radius, tile box, the API outputs, and for
+//      every tile of the box one returning atomic on the tile's counter followed by a store of
+//      the Gaussian id into the tile's segment (fixed capacity C ids per tile).
+//   2. rasterize_sum_fwd_kernel<FINALIZE> -- per tile: sorts its segment (ids arrive in atomic
+//      order; ascending order makes runs reproducible and lets the backward search lists),
+//      publishes the list length, returns the counter to zero, then rasterises.
+// Every launch costs ~2 us plus ~1-1.5 us per dependent memory round trip on this part, and a
+// 768x512 frame with 30k Gaussians is only a few us of arithmetic, so the design minimises
+// launches and dependent rounds rather than bytes.
+#include "host.h"
+#include "projection.h"
+
+// ------------------------------------------------------------------------------------------
+// projection and tile binning (one lane per Gaussian)
+// ------------------------------------------------------------------------------------------
+
+// RAW = the model's raw parameters come in and its activations are applied here:
+// means = tanh(_xyz), L = _cholesky + (0.5, 0, 0.5) (gaussianimage_cholesky.py:62,74,42).
+template <bool RAW>
+__global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
+    const float *__restrict__ means, const float *__restrict__ L, int N, int H, int W, int tiles_x,
+    int tiles_y, float center_bias, float *__restrict__ xys, float *__restrict__ depths,
+    int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
+    int *tile_count, int *seg, int C, int row0, int row1, const DevStatus *status,
+    volatile long long *h_status, long long generation)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
+    if (g >= N) return;
+    float l11 = L[3 * g], l21 = L[3 * g + 1], l22 = L[3 * g + 2];
+    float mx = means[2 * g], my = means[2 * g + 1];
+    if (RAW) {
+        mx = tanhf(mx);
+        my = tanhf(my);
+        l11 = l11 + 0.5f;
+        l22 = l22 + 0.5f;
+    }
+    float sxx = l11 * l11;
+    float sxy = l11 * l21;
+    float syy = l21 * l21 + l22 * l22;
+    project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths, radii,
+                 conics, num_tiles_hit, tile_count, seg, C, row0, row1);
+}
+
+// RAW: means = tanh(_xyz), scales = |_scaling + 0.5|, rotation = sigmoid(_rotation) * 2 * pi
+// (gaussianimage_rs.py:55-64).
+template <bool RAW>
+__global__ __launch_bounds__(256) void project_rs_fwd_kernel(
+    const float *__restrict__ means, const float *__restrict__ scales,
+    const float *__restrict__ rot, int N, int H, int W, int tiles_x, int tiles_y,
+    float center_bias, float *__restrict__ xys, float *__restrict__ depths,
+    int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
+    int *tile_count, int *seg, int C, int row0, int row1, const DevStatus *status,
+    volatile long long *h_status, long long generation)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
+    if (g >= N) return;
+    float theta = rot[g];
+    float s1 = scales[2 * g], s2 = scales[2 * g + 1];
+    float mx = means[2 * g], my = means[2 * g + 1];
+    if (RAW) {
+        mx = tanhf(mx);
+        my = tanhf(my);
+        s1 = fabsf(s1 + 0.5f);
+        s2 = fabsf(s2 + 0.5f);
+        theta = (1.0f / (1.0f + expf(-theta))) * 2.0f * 3.14159274f;
+    }
+    float s, c;
+    sincosf(theta, &s, &c);
+    float q1 = s1 * s1, q2 = s2 * s2;
+    float sxx = c * c * q1 + s * s * q2;
+    float sxy = c * s * (q1 - q2);
+    float syy = s * s * q1 + c * c * q2;
+    project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths, radii,
+                 conics, num_tiles_hit, tile_count, seg, C, row0, row1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Codec decode (decompress_wo_ec, gaussianimage_cholesky.py:161-166 / gaussianimage_rs.py:132-139):
+//   means    = tanh(float(xyz_half))
+//   cholesky = code * scale + beta, then + (0.5, 0, 0.5)       (quantize.py:86-87)
+//   scaling  = |code * scale + beta + 0.5|,  rotation = code * scale + beta
+//   colors   = sum over the residual-VQ layers q of codebook[q][index[g][q]]   (quantize.py:146-150)
+// Each product, sum and bound is rounded on its own, in the reference's order.  An index
+// outside the codebook is clamped into it (a corrupt stream gives wrong colours, not a fault).
+// ------------------------------------------------------------------------------------------
+struct DecodedGaussian {
+    float mx, my, a0, a1, a2, b0, col[3];
+};
+
+template <bool RS>
+__device__ __forceinline__ DecodedGaussian decode_gaussian(const gi2d_codec &cd, int g)
+{
+    DecodedGaussian d;
+    const __half2 h = reinterpret_cast<const __half2 *>(cd.xyz_half)[g];
+    d.mx = tanhf(__low2float(h));
+    d.my = tanhf(__high2float(h));
+    if (RS) {
+        d.a0 = fabsf((cd.cov_a_code[2 * g] * cd.cov_a_scale[0] + cd.cov_a_beta[0]) + 0.5f);
+        d.a1 = fabsf((cd.cov_a_code[2 * g + 1] * cd.cov_a_scale[1] + cd.cov_a_beta[1]) + 0.5f);
+        d.a2 = 0.f;
+        d.b0 = cd.cov_b_code[g] * cd.cov_b_scale[0] + cd.cov_b_beta[0];
+    } else {
+        d.a0 = (cd.cov_a_code[3 * g] * cd.cov_a_scale[0] + cd.cov_a_beta[0]) + 0.5f;
+        d.a1 = (cd.cov_a_code[3 * g + 1] * cd.cov_a_scale[1] + cd.cov_a_beta[1]) + 0.0f;
+        d.a2 = (cd.cov_a_code[3 * g + 2] * cd.cov_a_scale[2] + cd.cov_a_beta[2]) + 0.5f;
+        d.b0 = 0.f;
+    }
+    d.col[0] = d.col[1] = d.col[2] = 0.f;
+    for (int q = 0; q < cd.num_quantizers; ++q) {
+        int k = cd.color_index[(size_t)g * cd.num_quantizers + q];
+        k = min(max(k, 0), cd.codebook_size - 1);
+        const float *e = cd.codebooks + ((size_t)q * cd.codebook_size + k) * 3;
+        d.col[0] += e[0];
+        d.col[1] += e[1];
+        d.col[2] += e[2];
+    }
+    return d;
+}
+
+// The decoded operator inputs as tensors (what the reference's torch expressions produce).
+template <bool RS>
+__global__ __launch_bounds__(256) void decode_params_kernel(gi2d_codec cd, int N,
+                                                            float *__restrict__ means,
+                                                            float *__restrict__ cov_a,
+                                                            float *__restrict__ cov_b,
+                                                            float *__restrict__ colors)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const DecodedGaussian d = decode_gaussian<RS>(cd, g);
+    means[2 * g] = d.mx;
+    means[2 * g + 1] = d.my;
+    if (RS) {
+        cov_a[2 * g] = d.a0;
+        cov_a[2 * g + 1] = d.a1;
+        cov_b[g] = d.b0;
+    } else {
+        cov_a[3 * g] = d.a0;
+        cov_a[3 * g + 1] = d.a1;
+        cov_a[3 * g + 2] = d.a2;
+    }
+    colors[3 * g] = d.col[0];
+    colors[3 * g + 1] = d.col[1];
+    colors[3 * g + 2] = d.col[2];
+}
+
+// Decode fused into the projection: the frame's first launch reads the coded attributes, leaves
+// the decoded colours for the rasteriser and fills the tile lists.
+template <bool RS>
+__global__ __launch_bounds__(256) void project_decode_fwd_kernel(
+    gi2d_codec cd, float *__restrict__ colors, int N, int H, int W, int tiles_x, int tiles_y,
+    float center_bias, float *__restrict__ xys, float *__restrict__ depths,
+    int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
+    int *tile_count, int *seg, int C, int row0, int row1, const DevStatus *status,
+    volatile long long *h_status, long long generation)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
+    if (g >= N) return;
+    const DecodedGaussian d = decode_gaussian<RS>(cd, g);
+    colors[3 * g] = d.col[0];
+    colors[3 * g + 1] = d.col[1];
+    colors[3 * g + 2] = d.col[2];
+    float sxx, sxy, syy;
+    if (RS) {
+        float s, c;
+        sincosf(d.b0, &s, &c);
+        const float q1 = d.a0 * d.a0, q2 = d.a1 * d.a1;
+        sxx = c * c * q1 + s * s * q2;
+        sxy = c * s * (q1 - q2);
+        syy = s * s * q1 + c * c * q2;
+    } else {
+        sxx = d.a0 * d.a0;
+        sxy = d.a0 * d.a1;
+        syy = d.a1 * d.a1 + d.a2 * d.a2;
+    }
+    project_tail(g, d.mx, d.my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths,
+                 radii, conics, num_tiles_hit, tile_count, seg, C, row0, row1);
+}
+
+__global__ __launch_bounds__(256) void project_cholesky_bwd_kernel(
+    const float *__restrict__ L, int N, int H, int W, const float *__restrict__ v_xy,
+    const float *__restrict__ v_conic, float *__restrict__ v_means, float *__restrict__ v_L)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float l11 = L[3 * g], l21 = L[3 * g + 1], l22 = L[3 * g + 2];
+    float sxx = l11 * l11, sxy = l11 * l21, syy = l21 * l21 + l22 * l22;
+    float a, b, c, radius;
+    float vm0 = 0.f, vm1 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (cov_to_conic_radius(sxx, sxy, syy, a, b, c, radius)) {
+        float gxx, gxy, gyy;
+        conic_grad_to_cov_grad(a, b, c, v_conic[3 * g], v_conic[3 * g + 1], v_conic[3 * g + 2],
+                               gxx, gxy, gyy);
+        vm0 = 0.5f * (float)W * v_xy[2 * g];
+        vm1 = 0.5f * (float)H * v_xy[2 * g + 1];
+        o0 = 2.0f * l11 * gxx + l21 * gxy;
+        o1 = l11 * gxy + 2.0f * l21 * gyy;
+        o2 = 2.0f * l22 * gyy;
+    }
+    v_means[2 * g] = vm0;
+    v_means[2 * g + 1] = vm1;
+    v_L[3 * g] = o0;
+    v_L[3 * g + 1] = o1;
+    v_L[3 * g + 2] = o2;
+}
+
+__global__ __launch_bounds__(256) void project_rs_bwd_kernel(
+    const float *__restrict__ scales, const float *__restrict__ rot, int N, int H, int W,
+    const float *__restrict__ v_xy, const float *__restrict__ v_conic,
+    float *__restrict__ v_means, float *__restrict__ v_scales, float *__restrict__ v_rot)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float s, c;
+    sincosf(rot[g], &s, &c);
+    float s1 = scales[2 * g], s2 = scales[2 * g + 1];
+    float q1 = s1 * s1, q2 = s2 * s2;
+    float sxx = c * c * q1 + s * s * q2;
+    float sxy = c * s * (q1 - q2);
+    float syy = s * s * q1 + c * c * q2;
+    float a, b, cc, radius;
+    float vm0 = 0.f, vm1 = 0.f, vs0 = 0.f, vs1 = 0.f, vr = 0.f;
+    if (cov_to_conic_radius(sxx, sxy, syy, a, b, cc, radius)) {
+        float gxx, gxy, gyy;
+        conic_grad_to_cov_grad(a, b, cc, v_conic[3 * g], v_conic[3 * g + 1], v_conic[3 * g + 2],
+                               gxx, gxy, gyy);
+        vm0 = 0.5f * (float)W * v_xy[2 * g];
+        vm1 = 0.5f * (float)H * v_xy[2 * g + 1];
+        float gq1 = gxx * c * c + gxy * c * s + gyy * s * s;
+        float gq2 = gxx * s * s - gxy * c * s + gyy * c * c;
+        vs0 = 2.0f * s1 * gq1;
+        vs1 = 2.0f * s2 * gq2;
+        float dq = q1 - q2;
+        vr = dq * (-2.0f * c * s * gxx + (c * c - s * s) * gxy + 2.0f * c * s * gyy);
+    }
+    v_means[2 * g] = vm0;
+    v_means[2 * g + 1] = vm1;
+    v_scales[2 * g] = vs0;
+    v_scales[2 * g + 1] = vs1;
+    v_rot[g] = vr;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+static int check_proj_args(const void *a, const void *b, int N, int H, int W, int tiles_x,
+                           int tiles_y, const gi2d_conv *conv, const void *o0, const void *o1,
+                           const void *o2, const void *o3, const void *o4)
+{
+    if (N < 0 || H < 1 || W < 1 || !conv) return GI2D_E_INVALID;
+    if (tiles_x != cdiv(W, GI2D_BLOCK) || tiles_y != cdiv(H, GI2D_BLOCK)) return GI2D_E_INVALID;
+    if (N > 0 && (!a || !b || !o0 || !o1 || !o2 || !o3 || !o4)) return GI2D_E_INVALID;
+    return GI2D_OK;
+}
+
+// kind 0 = Cholesky (cov_a = L[N,3]), 1 = rotation-scale (cov_a = scales[N,2], cov_b = rotation).
+// raw = the model's raw parameters are given and activated inside the kernel.
+static int check_codec(int kind, const gi2d_codec *cd, int N)
+{
+    if ((kind != 0 && kind != 1) || !cd || N < 0) return GI2D_E_INVALID;
+    if (cd->num_quantizers < 1 || cd->num_quantizers > GI2D_MAX_VQ_LAYERS || cd->codebook_size < 1)
+        return GI2D_E_INVALID;
+    if (N == 0) return GI2D_OK;
+    if (!cd->xyz_half || !cd->cov_a_code || !cd->cov_a_scale || !cd->cov_a_beta ||
+        !cd->color_index || !cd->codebooks)
+        return GI2D_E_INVALID;
+    if (kind == 1 && (!cd->cov_b_code || !cd->cov_b_scale || !cd->cov_b_beta))
+        return GI2D_E_INVALID;
+    return GI2D_OK;
+}
+
+// codec != NULL: the inputs are the coded attributes (means / cov_a / cov_b unused) and the
+// decoded colours are written to colors_out.
+int project_impl(int kind, bool raw, const float *means, const float *cov_a,
+                        const float *cov_b, int N, int H, int W, int tiles_x, int tiles_y,
+                        const gi2d_conv *conv, float *xys, float *depths, int *radii,
+                        float *conics, int *num_tiles_hit, gi2d_workspace *ws, void *stream,
+                        const gi2d_codec *codec, float *colors_out)
+{
+    if (codec) {
+        int rcc = check_codec(kind, codec, N);
+        if (rcc != GI2D_OK) return rcc;
+        if (N > 0 && !colors_out) return GI2D_E_INVALID;
+        means = reinterpret_cast<const float *>(codec->xyz_half);
+        cov_a = codec->cov_a_code;
+        cov_b = codec->cov_b_code;
+    }
+    int rc = check_proj_args(means, cov_a, N, H, W, tiles_x, tiles_y, conv, xys, depths, radii,
+                             conics, num_tiles_hit);
+    if (rc != GI2D_OK) return rc;
+    if (kind == 1 && N > 0 && !cov_b) return GI2D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    bool fill = false;
+    DeviceGuard guard(ws ? ws->device : -1);
+    if (ws) {
+        if (!guard.ok) return GI2D_E_INVALID;
+        rc = begin_prefill(ws, N, tiles_x, tiles_y, st);
+        if (rc != GI2D_OK) return rc;
+        fill = ws->prefilled;
+    }
+    if (N == 0) return GI2D_OK;
+    int *cnt = fill ? ws->d_count : nullptr, *seg = fill ? ws->d_seg : nullptr;
+    const int C = fill ? ws->seg_cap : 0, r0 = fill ? ws->pre_r0 : 0, r1 = fill ? ws->pre_r1 : 0;
+    DevStatus *status = fill ? ws->d_status : nullptr;
+    long long *hs = fill ? ws->h_status_dev : nullptr;
+    const long long gen = fill ? ws->generation : 0;
+    const dim3 grid(cdiv(N, PG_THREADS)), block(PG_THREADS);
+#define GI2D_PROJ_ARGS N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii, conics, \
+                       num_tiles_hit, cnt, seg, C, r0, r1, status, hs, gen
+    if (codec) {
+        if (kind == 0)
+            project_decode_fwd_kernel<false><<<grid, block, 0, st>>>(*codec, colors_out, GI2D_PROJ_ARGS);
+        else
+            project_decode_fwd_kernel<true><<<grid, block, 0, st>>>(*codec, colors_out, GI2D_PROJ_ARGS);
+    } else if (kind == 0) {
+        if (raw)
+            project_cholesky_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, GI2D_PROJ_ARGS);
+        else
+            project_cholesky_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, GI2D_PROJ_ARGS);
+    } else {
+        if (raw)
+            project_rs_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, cov_b, GI2D_PROJ_ARGS);
+        else
+            project_rs_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, cov_b, GI2D_PROJ_ARGS);
+    }
+#undef GI2D_PROJ_ARGS
+    return launch_status();
+}
+
+
+extern "C" {
+
+int gi2d_project_cholesky_fwd(const float *means2d, const float *L_elements, int N, int H, int W,
+                              int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
+                              float *depths, int *radii, float *conics, int *num_tiles_hit,
+                              gi2d_workspace *ws, void *stream)
+{
+    return project_impl(0, false, means2d, L_elements, nullptr, N, H, W, tiles_x, tiles_y, conv,
+                        xys, depths, radii, conics, num_tiles_hit, ws, stream);
+}
+
+int gi2d_project_rs_fwd(const float *means2d, const float *scales, const float *rotation, int N,
+                        int H, int W, int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
+                        float *depths, int *radii, float *conics, int *num_tiles_hit,
+                        gi2d_workspace *ws, void *stream)
+{
+    return project_impl(1, false, means2d, scales, rotation, N, H, W, tiles_x, tiles_y, conv, xys,
+                        depths, radii, conics, num_tiles_hit, ws, stream);
+}
+
+int gi2d_project_cholesky_bwd(const float *means2d, const float *L_elements, int N, int H, int W,
+                              const float *v_xys, const float *v_conics, float *v_means2d,
+                              float *v_L_elements, void *stream)
+{
+    (void)means2d;
+    if (N < 0 || H < 1 || W < 1) return GI2D_E_INVALID;
+    if (N == 0) return GI2D_OK;
+    if (!L_elements || !v_xys || !v_conics || !v_means2d || !v_L_elements) return GI2D_E_INVALID;
+    project_cholesky_bwd_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
+        L_elements, N, H, W, v_xys, v_conics, v_means2d, v_L_elements);
+    return launch_status();
+}
+
+int gi2d_project_rs_bwd(const float *means2d, const float *scales, const float *rotation, int N,
+                        int H, int W, const float *v_xys, const float *v_conics, float *v_means2d,
+                        float *v_scales, float *v_rotation, void *stream)
+{
+    (void)means2d;
+    if (N < 0 || H < 1 || W < 1) return GI2D_E_INVALID;
+    if (N == 0) return GI2D_OK;
+    if (!scales || !rotation || !v_xys || !v_conics || !v_means2d || !v_scales || !v_rotation)
+        return GI2D_E_INVALID;
+    project_rs_bwd_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(
+        scales, rotation, N, H, W, v_xys, v_conics, v_means2d, v_scales, v_rotation);
+    return launch_status();
+}
+
+int gi2d_decode_params(int kind, const gi2d_codec *codec, int N, float *means2d, float *cov_a,
+                       float *cov_b, float *colors, void *stream)
+{
+    int rc = check_codec(kind, codec, N);
+    if (rc != GI2D_OK) return rc;
+    if (N == 0) return GI2D_OK;
+    if (!means2d || !cov_a || !colors || (kind == 1 && !cov_b)) return GI2D_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0)
+        decode_params_kernel<false><<<cdiv(N, 256), 256, 0, st>>>(*codec, N, means2d, cov_a, cov_b,
+                                                                  colors);
+    else
+        decode_params_kernel<true><<<cdiv(N, 256), 256, 0, st>>>(*codec, N, means2d, cov_a, cov_b,
+                                                                 colors);
+    return launch_status();
+}
+
+}  // extern "C"

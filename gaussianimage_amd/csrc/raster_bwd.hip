@@ -1,0 +1,260 @@
+// raster_bwd.hip -- rasterize_gaussians_sum backward: per-tile partial sums, then their gather.
+#include "gather.h"
+#include "host.h"
+#include "support.h"
+#include "tiles.h"
+
+// ------------------------------------------------------------------------------------------
+// rasterize_sum backward.
+//
+// Pass 1 (one workgroup per tile): a quad of lanes per list entry.  The quad walks only the
+// pixels of the entry's support rectangle (bounding box of the ellipse alpha >= alpha_min),
+// round-robin over its four lanes, keeps the entry's nine partial sums in registers, adds the
+// four lanes with two DPP steps and writes the sums to the entry's own slot of a [slots][9]
+// slab -- no cross-lane tree, no atomics -- and notes the slot in a small per-Gaussian table.
+// Pass 2 (one lane per Gaussian): adds the Gaussian's slots in tile order; slots of the first
+// SLOT_TAB tiles come from the table, the rest by binary search (lists ascend in Gaussian id).
+// ------------------------------------------------------------------------------------------
+
+// sum over the LPE (4, 8 or 16) neighbouring lanes of an entry's group, result in every lane
+template <int LPE>
+__device__ __forceinline__ float group_sum(float v)
+{
+    v = quad_sum(v);
+    if (LPE >= 8) v = v + dpp_mov<0x141>(v);   // row_half_mirror: lane i <-> 7-i of each 8
+    if (LPE >= 16) v = v + dpp_mov<0x140>(v);  // row_mirror: lane i <-> 15-i of each 16
+    return v;
+}
+
+// The batches of one tile with LPE lanes per list entry (256 / LPE entries per batch).
+template <int LPE>
+__device__ __forceinline__ void bwd_tile(
+    const int *__restrict__ lst, const int *s_first, int n_raw, size_t slot0, int tx, int ty,
+    const float4 *s_v, const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
+    const gi2d_conv &cv, int cull, float *__restrict__ partials, int *__restrict__ slot_tab)
+{
+    constexpr int EPB = 256 / LPE;  // entries per batch
+    const int tid = threadIdx.x;
+    const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
+    const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
+    const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
+    const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
+    const int q = tid & (LPE - 1);
+    for (int base = 0; base < n_raw; base += EPB) {
+        const int e = base + tid / LPE;
+        float acc[PART_STRIDE];
+#pragma unroll
+        for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
+        int gid = 0, rad = 0;
+        float gx = 0.f, gy = 0.f;
+        if (e < n_raw) {
+            gid = base == 0 ? s_first[e] : lst[e];  // (the first 64 ids are already here)
+            gx = xys[2 * gid];
+            gy = xys[2 * gid + 1];
+            rad = radii[gid];
+            const float a = conics[3 * gid], b = conics[3 * gid + 1], c = conics[3 * gid + 2];
+            const float op = opacity[gid];
+            const float cr = colors[3 * gid], cg = colors[3 * gid + 1], cb = colors[3 * gid + 2];
+            int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
+            if (cull) support_rect(gx, gy, a, b, c, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
+            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+            const int cnt = (w > 0 && h > 0) ? w * h : 0;
+            // The lanes of the group take the rectangle's pixels round-robin.  LPE / w and
+            // q / w for w in 1..16 from the hardware reciprocal (exact here: the quotients'
+            // fractional parts are multiples of 1/w, well clear of the 1-ulp error).
+            const float rw = __builtin_amdgcn_rcpf((float)max(w, 1));
+            const int step_y = cnt ? (int)((float)LPE * rw + 1.0e-3f) : 0;
+            const int step_x = cnt ? LPE - step_y * w : 0;
+            const int qy = (int)(((float)q + 0.5f) * rw);
+            int x = x0 + q - qy * w, y = y0 + qy;
+            const float pa = (-0.5f * LOG2E) * a, pb = (-LOG2E) * b, pc = (-0.5f * LOG2E) * c;
+            for (int k = q; k < cnt; k += LPE) {
+                const float dx = gx - (ox + (float)x), dy = gy - (oy + (float)y);
+                const float p = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
+                const float ex = __builtin_amdgcn_exp2f(p);
+                const float oe = op * ex;
+                const float alpha = fminf(cv.alpha_cap, oe);
+                const bool on = !(p > 0.f || alpha < cv.alpha_min);
+                const float4 v = s_v[y * GI2D_BLOCK + x];
+                const float am = on ? alpha : 0.f;
+                acc[5] = __builtin_fmaf(am, v.x, acc[5]);
+                acc[6] = __builtin_fmaf(am, v.y, acc[6]);
+                acc[7] = __builtin_fmaf(am, v.z, acc[7]);
+                const float v_alpha = __builtin_fmaf(cb, v.z, __builtin_fmaf(cg, v.y, cr * v.x));
+                const bool live = on && !(oe > cv.alpha_cap);  // a capped alpha is a constant
+                const float va = live ? v_alpha : 0.f;
+                const float vs = -oe * va;
+                acc[8] = __builtin_fmaf(ex, va, acc[8]);
+                // moments of vs over the rectangle; the conic enters once, after the loop
+                const float hx = vs * dx, hy = vs * dy;
+                acc[0] += hx;
+                acc[1] += hy;
+                acc[2] = __builtin_fmaf(hx, dx, acc[2]);
+                acc[3] = __builtin_fmaf(hx, dy, acc[3]);
+                acc[4] = __builtin_fmaf(hy, dy, acc[4]);
+                x += step_x;
+                y += step_y;
+                if (x > x1) {
+                    x -= w;
+                    ++y;
+                }
+            }
+            // v_xy = sum vs * (conic . d) = conic . (sum vs * d); v_conic = (1/2, 1, 1/2) * moments
+            const float m0 = acc[0], m1 = acc[1];
+            acc[0] = __builtin_fmaf(b, m1, a * m0);
+            acc[1] = __builtin_fmaf(c, m1, b * m0);
+            acc[2] *= 0.5f;
+            acc[4] *= 0.5f;
+        }
+#pragma unroll
+        for (int k = 0; k < PART_STRIDE; ++k) acc[k] = group_sum<LPE>(acc[k]);
+        if (e < n_raw && q == 0) {
+            float *dst = partials + (slot0 + e) * PART_STRIDE;
+#pragma unroll
+            for (int k = 0; k < PART_STRIDE; ++k) dst[k] = acc[k];
+            // where pass 2 finds this slot without searching: index of this tile in the
+            // Gaussian's own (band-clipped) tile box, first SLOT_TAB tiles only
+            if (rad > 0) {
+                TileBox box = tile_box(gx, gy, (float)rad, tiles_x, tiles_y);
+                const int by0 = max(box.y0, row0);
+                const int kb = (ty - by0) * (box.x1 - box.x0) + (tx - box.x0);
+                if (kb >= 0 && kb < SLOT_TAB) slot_tab[(size_t)gid * SLOT_TAB + kb] = e;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
+    const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
+    const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
+    int T, gi2d_conv cv, int cull, const float *__restrict__ v_out,
+    float *__restrict__ partials, int *__restrict__ slot_tab)
+{
+    __shared__ float4 s_v[256];
+    __shared__ int s_first[64];
+    const int tid = threadIdx.x;
+    const int t = xcd_tile(blockIdx.x, T);
+    const int *lst = seg + (size_t)t * C;
+    // the first 64 ids before the length is known (a segment always has C >= 64 words)
+    if (tid < 64) s_first[tid] = lst[tid];
+    const int n_raw = tile_len[t];
+    if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
+    const size_t slot0 = (size_t)t * C;
+    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
+    {
+        const int j = tx * GI2D_BLOCK + (tid & 15), i = ty * GI2D_BLOCK + (tid >> 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < H && j < W) {
+            const float *p = v_out + 3 * ((size_t)(i - row0 * GI2D_BLOCK) * W + j);
+            v.x = p[0];
+            v.y = p[1];
+            v.z = p[2];
+        }
+        s_v[tid] = v;
+    }
+    __syncthreads();
+    // a short list gets more lanes per entry: its rectangles are walked in fewer steps
+#define GI2D_BWD_TILE(LPE)                                                                      \
+    bwd_tile<LPE>(lst, s_first, n_raw, slot0, tx, ty, s_v, xys, radii, conics, colors, opacity, \
+                  H, W, tiles_x, tiles_y, row0, cv, cull, partials, slot_tab)
+    if (n_raw <= 16) GI2D_BWD_TILE(16);
+    else if (n_raw <= 32) GI2D_BWD_TILE(8);
+    else GI2D_BWD_TILE(4);
+#undef GI2D_BWD_TILE
+}
+
+__global__ __launch_bounds__(256) void gather_grads_kernel(
+    const float *__restrict__ xys, const int *__restrict__ radii, int N, int tiles_x, int tiles_y,
+    int row0, int row1, const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
+    const float *__restrict__ partials, const int *__restrict__ slot_tab,
+    float *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_colors,
+    float *__restrict__ v_opacity)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float acc[PART_STRIDE];
+    gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
+                    tile_len, seg, C, partials, slot_tab, acc);
+    v_xy[2 * g] = acc[0];
+    v_xy[2 * g + 1] = acc[1];
+    v_conic[3 * g] = acc[2];
+    v_conic[3 * g + 1] = acc[3];
+    v_conic[3 * g + 2] = acc[4];
+    v_colors[3 * g] = acc[5];
+    v_colors[3 * g + 1] = acc[6];
+    v_colors[3 * g + 2] = acc[7];
+    v_opacity[g] = acc[8];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+// Backward pass 1 (per-tile partial sums into the slab); shared by the operator backward and
+// the fused fitting step.
+int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
+                            const float *conics, const float *colors, const float *opacity, int N,
+                            int H, int W, const gi2d_conv *conv, const float *v_out,
+                            hipStream_t st)
+{
+    int rc = finalize_lists(ws, st);
+    if (rc != GI2D_OK) return rc;
+    const int64_t slots = (int64_t)ws->tiles_cap * ws->seg_cap;
+    if (ws->part_slots < slots) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (ws->d_partials) (void)hipFree(ws->d_partials);
+        ws->d_partials = nullptr;
+        ws->part_slots = 0;
+        HIP_TRY(hipMalloc(&ws->d_partials, sizeof(float) * PART_STRIDE * (size_t)slots));
+        ws->part_slots = slots;
+    }
+    if (ws->slot_cap < N) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (ws->d_slot_tab) (void)hipFree(ws->d_slot_tab);
+        ws->d_slot_tab = nullptr;
+        ws->slot_cap = 0;
+        HIP_TRY(hipMalloc(&ws->d_slot_tab, sizeof(int) * SLOT_TAB * (size_t)N));
+        HIP_TRY(hipMemset(ws->d_slot_tab, 0, sizeof(int) * SLOT_TAB * (size_t)N));
+        ws->slot_cap = N;
+    }
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (T > 0) {
+        rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(
+            ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, colors, opacity, H, W,
+            ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull, v_out,
+            ws->d_partials, ws->d_slot_tab);
+        rc = launch_status();
+    }
+    return rc;
+}
+
+
+extern "C" {
+
+int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radii,
+                           const float *conics, const float *colors, const float *opacity, int N,
+                           int H, int W, const gi2d_conv *conv, const float *v_out, float *v_xys,
+                           float *v_conics, float *v_colors, float *v_opacity, void *stream)
+{
+    int rc = check_raster_args(ws, N, H, W, conv);
+    if (rc != GI2D_OK) return rc;
+    if (N == 0) return GI2D_OK;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (!xys || !radii || !conics || !colors || !opacity || (!v_out && T > 0) || !v_xys ||
+        !v_conics || !v_colors || !v_opacity)
+        return GI2D_E_INVALID;
+    DeviceGuard guard(ws->device);
+    hipStream_t st = (hipStream_t)stream;
+    rc = raster_bwd_pass1(ws, xys, radii, conics, colors, opacity, N, H, W, conv, v_out, st);
+    if (rc != GI2D_OK) return rc;
+    gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(
+        xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, ws->d_len, ws->d_seg,
+        ws->seg_cap, ws->d_partials, ws->d_slot_tab, v_xys, v_conics, v_colors, v_opacity);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -5,7 +5,7 @@
 error behaviour of the operators the reference imports
 (/root/reference/gaussianimage_cholesky.py:1-2,77,81-82;
 /root/reference/gaussianimage_rs.py:1-2,75-77) and run on the HIP kernels of
-``csrc/gi2d.hip`` through the C ABI.  PyTorch is used for device memory, the
+``csrc/*.hip`` through the C ABI.  PyTorch is used for device memory, the
 current stream and autograd bookkeeping only.
 """
 import ctypes
