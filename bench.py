@@ -117,7 +117,17 @@ def bench_forward(pipe, inputs, steps, warmup, sync_all):
     sync_all()
     el = time.perf_counter() - t0
     raster_ms = sorted(a.elapsed_time(b) for a, b in ev[::4])
-    return el, raster_ms
+    # What an event pair measures with NOTHING between the two records, on the same busy
+    # stream (outside the timed region): the bracket's own share of a bracketed launch.
+    empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+             for _ in range(48)]
+    for a, b in empty:
+        run()
+        a.record()
+        b.record()
+    sync_all()
+    empty_ms = sorted(a.elapsed_time(b) for a, b in empty)
+    return el, raster_ms, empty_ms[len(empty_ms) // 2]
 
 
 def bench_region(fn, steps, warmup):
@@ -265,7 +275,7 @@ def bench_concurrent(name, inputs, device, steps, streams=4):
     return {"fps_%d_streams" % streams: steps / (time.perf_counter() - t0)}
 
 
-def bench_fused_fit(name, device, steps):
+def bench_fused_fit(name, device, steps, concurrent=True):
     """The fused fitting iteration (gaussianimage_amd/fit.py): forward, L2 loss, backward and
     Adan step in four launches on the raw parameters, no host synchronisation inside the loop."""
     from gaussianimage_amd import synth
@@ -284,6 +294,8 @@ def bench_fused_fit(name, device, steps):
     ms = (time.perf_counter() - t0) / steps * 1e3
     out = {"fused_train_step_ms": ms, "fused_train_iters_per_s": 1e3 / ms,
            "fused_train_psnr_after_%d_iters" % (steps + 10): fit.psnr()}
+    if not concurrent:
+        return out
     # several images fitted at once (the reference fits the images of a dataset one after the
     # other, /root/reference/train.py:306-316): one fitter per HIP stream, default priority
     streams = 4
@@ -314,6 +326,9 @@ def main():
     ap.add_argument("--workload", default="kodak30k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-concurrent", action="store_true",
+                    help="skip the multi-stream extras (their overlapping kernels blur a "
+                         "profiler's per-kernel durations)")
     ap.add_argument("--raster-ppl", type=int, default=0, choices=[0, 1, 2, 4],
                     help="pixels per lane of the forward rasteriser (0 = the library's choice)")
     args = ap.parse_args()
@@ -356,7 +371,8 @@ def main():
     I = pipe.intersections()
     P, T = H * W, pipe.tiles_x * pipe.tiles_y
 
-    el, raster_ms = bench_forward(pipe, inputs, args.steps, args.warmup, sync_all)
+    el, raster_ms, empty_bracket_ms = bench_forward(pipe, inputs, args.steps, args.warmup,
+                                                    sync_all)
     if distributed:
         t = torch.tensor([el], dtype=torch.float64,
                          device=device if dist.get_backend() == "nccl" else "cpu")
@@ -389,7 +405,8 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": bytes_raster,
                      "avg_launch_ms": raster_avg_ms,
-                     "median_launch_ms": raster_ms[len(raster_ms) // 2]},
+                     "median_launch_ms": raster_ms[len(raster_ms) // 2],
+                     "empty_event_bracket_ms": empty_bracket_ms},
     }
 
     if not args.no_extras and rank == 0:
@@ -424,10 +441,12 @@ def main():
         # and transcendental work on cache-resident data, not HBM traffic.
         pairs = I * 256
         ex["pair_evals_per_s"] = pairs / (raster_avg_ms * 1e-3)
-        ex.update(bench_concurrent(args.workload, inputs, device, max(args.steps, 200)))
+        if not args.no_concurrent:
+            ex.update(bench_concurrent(args.workload, inputs, device, max(args.steps, 200)))
         ex.update(bench_model_loops(args.workload, device, k))
         ex.update(bench_decode(args.workload, device, k))
-        ex.update(bench_fused_fit(args.workload, device, max(k, 100)))
+        ex.update(bench_fused_fit(args.workload, device, max(k, 100),
+                                  concurrent=not args.no_concurrent))
         result["extras"] = ex
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         result["cpu_baseline"] = time_cpu_oracle(args.workload)

@@ -8,4 +8,4 @@ cat gpurun_out/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kt -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $R/gpurun_out/prof/run.log 2>&1 || { tail -20 $R/gpurun_out/prof/run.log; exit 1; }
 ls -R $R/gpurun_out/prof | head -30
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o full -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $R/gpurun_out/prof/run_full.log 2>&1 || { tail -20 $R/gpurun_out/prof/run_full.log; exit 1; }
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o full -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-concurrent > $R/gpurun_out/prof/run_full.log 2>&1 || { tail -20 $R/gpurun_out/prof/run_full.log; exit 1; }

@@ -37,7 +37,7 @@ def norm(k):
 # the timed path of bench.py runs the <true> (finalising) instantiation of the forward rasteriser
 flat = {}
 for k, v in out.items():
-    if norm(k) not in flat or "<true>" in k:
+    if norm(k) not in flat or "<true" in k:
         flat[norm(k)] = v["total"]
 data[workload] = flat
 data[workload + "_detail"] = out
