@@ -645,3 +645,45 @@ def test_masked_opacities_and_their_gradient(ops, oracle):
     assert _maxrel(_np(o.grad), r[3].reshape(N, 1)) <= GRAD_RTOL
     dead = (opac == 0).reshape(-1).numpy()
     assert dead.sum() > 100 and not _np(c.grad)[dead].any()
+
+
+@pytest.mark.parametrize("H,W,N", [(768, 1020, 50000), (2160, 3840, 200000)])
+def test_full_size_backward_properties(ops, oracle, H, W, N):
+    """BASELINE configs 4 and 5 sizes, forward + backward, through properties that need no
+    oracle pass: the image is linear in the colours, so (a) the colour gradient does not depend
+    on the colours (bit for bit), (b) <v_colors, d> equals the change of the loss along any
+    colour direction d, (c) the Gaussians split into two halves render to images that add up to
+    the full frame, with gradients that are those of the full frame."""
+    means, L, col, op = synth.cholesky_inputs(N, seed=2)
+    tb = oracle.tile_bounds(H, W)
+    g = torch.Generator().manual_seed(3)
+    proj = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+    xys, depths, radii, conics, nth = proj
+    opa = (0.3 + 0.7 * torch.rand(N, 1, generator=g)).to(DEV)
+    v_out = torch.randn(H, W, 3, generator=g).to(DEV)
+
+    def run(colors, keep=None):
+        x = xys.detach().clone().requires_grad_(True)
+        c = colors.clone().requires_grad_(True)
+        o = opa.clone() if keep is None else opa * keep
+        img = ops.rasterize_gaussians_sum(x, depths, radii, conics, nth, c, o, H, W, 16, 16)
+        loss = (img * v_out).sum()
+        loss.backward()
+        return img.detach(), float(loss.detach()), x.grad, c.grad
+
+    c1 = col.to(DEV)
+    c2 = torch.rand(N, 3, generator=g).to(DEV)
+    img1, l1, gx1, gc1 = run(c1)
+    img2, l2, gx2, gc2 = run(c2)
+    assert torch.equal(gc1, gc2)                                        # (a)
+    d = c2 - c1
+    lhs, rhs = l2 - l1, float((gc1.double() * d.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0)        # (b)
+    even = (torch.arange(N, device=DEV) % 2 == 0).float().view(N, 1)
+    img_e, _, gx_e, gc_e = run(c1, even)
+    img_o, _, gx_o, gc_o = run(c1, 1 - even)
+    assert float((img_e + img_o - img1).abs().max()) <= 2e-5            # (c)
+    m = even.bool().view(-1)
+    assert torch.equal(gc_e[m], gc1[m]) and torch.equal(gc_o[~m], gc1[~m])
+    assert not gc_e[~m].any() and not gx_e[~m].any()
+    assert _maxrel(_np(gx_e + gx_o), _np(gx1)) <= 1e-5
