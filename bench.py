@@ -453,17 +453,37 @@ def main():
         result["cpu_baseline"]["gpu_over_cpu"] = fps / result["cpu_baseline"]["value"]
 
     if distributed:
-        try:
-            from gaussianimage_amd.sharding import bench_tile_row_sharded
-            shard = bench_tile_row_sharded(device, rank, world, steps=max(20, args.steps // 4),
-                                           warmup=5)
-            if rank == 0:
-                result["tile_row_sharded"] = shard
-        except Exception as e:  # the headline line must still print
-            if rank == 0:
-                result["tile_row_sharded"] = {"error": repr(e)}
-        dist.barrier()
-        dist.destroy_process_group()
+        # Secondary measurement: one 4K frame split by tile rows.  It runs in a watched thread:
+        # a collective that never completes (or a rank that died) must not cost the headline
+        # line, so after GI2D_SHARD_TIMEOUT_S the ranks stop waiting, rank 0 prints what it has,
+        # and every rank leaves without joining the stuck work.
+        import threading
+        box = {}
+
+        def sharded():
+            try:
+                torch.cuda.set_device(local_rank)
+                from gaussianimage_amd.sharding import bench_tile_row_sharded
+                box["result"] = bench_tile_row_sharded(device, rank, world,
+                                                       steps=max(20, args.steps // 4), warmup=5)
+                dist.barrier()
+                box["done"] = True
+            except Exception as e:
+                box["result"] = {"error": repr(e)}
+
+        th = threading.Thread(target=sharded, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("GI2D_SHARD_TIMEOUT_S", "150")))
+        if th.is_alive():
+            box.setdefault("result", {"error": "timed out waiting for the ranks"})
+        if rank == 0:
+            result["tile_row_sharded"] = box.get("result", {"error": "no result"})
+            print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        if box.get("done"):
+            dist.destroy_process_group()
+            return
+        os._exit(0)  # stuck or failed collective: do not wait for it at interpreter exit
     if rank == 0:
         print(json.dumps(result), flush=True)
 
