@@ -17,11 +17,16 @@
 // ------------------------------------------------------------------------------------------
 
 // Tile counts from which the forward rasteriser switches to 2 / 4 pixels per lane.  Measured on
-// MI355X: a 3840x2160 frame with ~15 Gaussians per tile (32 400 tiles) is 20 % faster with 2,
-// 768x512 frames (1536 tiles, ~48 per tile) are 15 % slower.
-#define GI2D_PPL2_MIN_TILES 8192
-#define GI2D_PPL4_MIN_TILES INT_MAX  // never chosen automatically: 2 was the best large-frame shape
-#define FWD_LDS_INTS 2816  // 11 KB of LDS: the staging records, or the sort buffer of a long list
+// MI355X (kernel time, first pass): 3840x2160 / 200k (32 400 tiles, ~15 Gaussians per tile)
+// 59 / 44 / 38 us with 1 / 2 / 4; ~1020x768 / 50k (10 752 tiles) 14.6 / 14.6 / 20.3 us;
+// 768x512 / 30k (1536 tiles, ~48 per tile) 10 / 11.5 / 18 us.
+#define GI2D_PPL2_MIN_TILES 12288
+#define GI2D_PPL4_MIN_TILES 20480
+// LDS words per staged entry: two float4 records, blue, quadrant mask, id.  A workgroup of
+// BATCH lanes holds BATCH entries (11 KB for 256 lanes, 2.75 KB for 64: the small shapes need
+// the small footprint to reach their occupancy); the same words are the sort buffer of a list
+// longer than one batch.
+#define FWD_LDS_INTS_PER_ENTRY 11
 
 // L2 = true adds the fitting loop's epilogue (gaussianimage_cholesky.py:83-85,104 with
 // utils.py:24-25): clamp to [0,1], L2 loss against the target (stored [3,H,W] like the model's
@@ -53,13 +58,14 @@ __global__ __launch_bounds__(256 / PPL) void rasterize_sum_fwd_kernel(
     constexpr int BATCH = 256 / PPL;            // lanes of the workgroup = entries staged at once
     constexpr int NX = 3 * (SETS - 1);          // extra colour floats per entry
     constexpr int NX4 = (NX + 3) / 4;           // ... in float4 records
+    constexpr int FWD_LDS_INTS = FWD_LDS_INTS_PER_ENTRY * BATCH;
     __shared__ __attribute__((aligned(16))) int smem[FWD_LDS_INTS];
     __shared__ float4 s_x[NX4 ? NX4 * 256 : 1];  // extra sets: record q of entry k at [q*256+k]
     float4 *s_a = reinterpret_cast<float4 *>(smem);         // gx, gy, -0.5*a*log2e, -b*log2e
-    float4 *s_b = reinterpret_cast<float4 *>(smem + 1024);  // -0.5*c*log2e, opacity, r, g
-    float *s_c = reinterpret_cast<float *>(smem + 2048);    // b
-    int *s_m = smem + 2304;                                 // quadrant mask (bit = 2*qy + qx)
-    int *s_id = smem + 2560;                                // ids of the batch (rank sort)
+    float4 *s_b = reinterpret_cast<float4 *>(smem + 4 * BATCH);  // -0.5*c*log2e, opacity, r, g
+    float *s_c = reinterpret_cast<float *>(smem + 8 * BATCH);    // b
+    int *s_m = smem + 9 * BATCH;                            // quadrant mask (bit = 2*qy + qx)
+    int *s_id = smem + 10 * BATCH;                          // ids of the batch (rank sort)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_tile(blockIdx.x, T);
     const int tx = t % tiles_x, ty = row0 + t / tiles_x;
