@@ -444,6 +444,16 @@ def main():
         if not args.no_concurrent:
             ex.update(bench_concurrent(args.workload, inputs, device, max(args.steps, 200)))
         ex.update(bench_model_loops(args.workload, device, k))
+        if args.workload == "kodak30k":
+            # the one-GPU point of the tile-row scaling series (3840x2160 / 200k Gaussians)
+            big = FramePipeline(*[WORKLOADS["uhd200k"][i] for i in (2, 0, 1)],
+                                kind=WORKLOADS["uhd200k"][3], device=device)
+            big_in = make_inputs("uhd200k", device, seed=1)
+            big_v = torch.randn(WORKLOADS["uhd200k"][0], WORKLOADS["uhd200k"][1], 3, device=device)
+            ex["uhd200k_1gpu_forward_ms"] = bench_region(lambda: big.forward(*big_in), 50, 5)
+            ex["uhd200k_1gpu_fwd_bwd_ms"] = bench_region(
+                lambda: (big.forward(*big_in), big.backward(*big_in, big_v)), 50, 5)
+            del big, big_in, big_v
         ex.update(bench_decode(args.workload, device, k))
         ex.update(bench_fused_fit(args.workload, device, max(k, 100),
                                   concurrent=not args.no_concurrent))

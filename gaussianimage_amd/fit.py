@@ -50,6 +50,7 @@ class FusedFitter:
                           ("exp_avg", "exp_avg_sq", "exp_avg_diff", "neg_pre_grad")}
                       for k, p in self.params.items()}
         self.step_count = 0
+        self.overflowed_frames = 0  # iterations in which some tile list overflowed (see forward)
         self.ws = Workspace(d)
         self.conv = _lib.default_conv(**get_conventions())
         self.tiles = ((W + BLOCK - 1) // BLOCK) * ((H + BLOCK - 1) // BLOCK)
@@ -94,6 +95,12 @@ class FusedFitter:
                 not gt_image.is_contiguous() or gt_image.numel() != 3 * self.H * self.W:
             raise ValueError("gt_image must be a contiguous float32 [1,3,H,W] tensor on the device")
         rc = lib.gi2d_fit_forward(*self._fwd_args, _ptr(gt_image), *self._fwd_tail, self._stream)
+        if rc == _lib.GI2D_E_PREV_OVERFLOW:
+            # An EARLIER iteration outgrew a tile list (Gaussians grow while fitting): its
+            # overflowed tiles contributed no loss gradient for that one step, the lists have
+            # been enlarged since, and this iteration is complete.  Nothing to repair in a fit.
+            self.overflowed_frames += 1
+            rc = 0
         check(rc, "gi2d_fit_forward")
 
     def step(self, gt_image):

@@ -84,7 +84,8 @@ class CholeskyImageModel(_Base):
                 self.BLOCK_H, self.BLOCK_W, background=self.background)
             alpha = alpha.mean(dim=-1, keepdim=True)
             return {"render": self._image(img), "gauss_render": self._image(gauss),
-                    "alpha_map": alpha.view(-1, self.H, self.W, 1).permute(0, 3, 1, 2).contiguous()}
+                    "alpha_map": alpha.view(-1, self.H, self.W, 1).permute(0, 3, 1, 2).contiguous(),
+                    "final_opacities": opacities}
         out = {"render": self._image(rasterize_gaussians_sum(
             *args, colors, opacities, self.H, self.W, self.BLOCK_H, self.BLOCK_W, **kw))}
         if self.passes >= 3:
@@ -95,6 +96,7 @@ class CholeskyImageModel(_Base):
                                             self.W, self.BLOCK_H, self.BLOCK_W, **kw)
             alpha = alpha.mean(dim=-1, keepdim=True)
             out["alpha_map"] = alpha.view(-1, self.H, self.W, 1).permute(0, 3, 1, 2).contiguous()
+            out["final_opacities"] = opacities
         return out
 
 

@@ -80,3 +80,32 @@ def test_fused_fit_reduces_the_loss():
         fit.step(gt)
     last = fit.psnr()
     assert last > first + 6.0, (first, last)
+
+
+@pytest.mark.gpu
+def test_growing_gaussians_do_not_stop_a_fit():
+    """Footprints that suddenly outgrow the tile lists' capacity (sized from earlier iterations)
+    cost the overflowed tiles one step's gradient, never a NaN or an exception: the workspace
+    grows and the fit goes on."""
+    from gaussianimage_amd import synth
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N = 64, 80, 3000
+    torch.manual_seed(2)
+    fit = FusedFitter(N, H, W, kind="cholesky", device="cuda:0")
+    gt = synth.target_image(H, W).to("cuda:0")
+    for _ in range(5):
+        fit.step(gt)
+    cap0 = fit.ws.info()["capacity"]
+    fit.params["_cholesky"].mul_(5.0).add_(2.0)   # every Gaussian now covers many tiles
+    for _ in range(6):
+        fit.step(gt)
+    torch.cuda.synchronize()  # the host runs ahead of the device: let the reports arrive
+    for _ in range(2):
+        fit.step(gt)
+    torch.cuda.synchronize()
+    assert fit.overflowed_frames >= 1
+    assert fit.ws.info()["capacity"] > cap0
+    for p in fit.params.values():
+        assert torch.isfinite(p).all()
+    fit.forward(gt)
+    assert torch.isfinite(fit.v_image).all() and fit.loss() == fit.loss()

@@ -563,7 +563,7 @@ def test_harness_fused_passes_equal_the_three_pass_forward(ops, oracle):
     b.random_colors = a.random_colors
     with torch.no_grad():
         oa, ob = a(), b()
-    assert set(oa) == set(ob) == {"render", "gauss_render", "alpha_map"}
+    assert set(oa) == set(ob) == {"render", "gauss_render", "alpha_map", "final_opacities"}
     for k in oa:
         assert torch.equal(oa[k], ob[k]), k
 
