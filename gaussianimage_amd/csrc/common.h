@@ -23,7 +23,12 @@
 #define CNT_STRIDE 32
 #define LOG2E 1.4426950408889634f
 #define PART_STRIDE 9  // backward partial sums per (tile, Gaussian): v_xy 2, v_conic 3, v_rgb 3, v_op 1
-#define SLOT_TAB 4     // slots per Gaussian remembered by backward pass 1 (boxes are mostly <= 2x2)
+// Backward pass 1 leaves the partial sums of a Gaussian's first GSLOTS tiles (row-major in its
+// tile box; boxes are mostly <= 2x2) in the Gaussian's OWN slots, GSLOT_STRIDE floats each: the 9
+// sums and the stamp of the binning they belong to.  Pass 2 reads them in one round, with no
+// look-up; further tiles go through the per-tile slab and a search.
+#define GSLOTS 4
+#define GSLOT_STRIDE 10
 
 // ------------------------------------------------------------------------------------------
 // device helpers

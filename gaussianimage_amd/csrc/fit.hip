@@ -17,12 +17,12 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
     AdanTensors T, AdanScalars h, const float *__restrict__ xys, const int *__restrict__ radii,
     int N, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
     const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
-    const float *__restrict__ partials, const int *__restrict__ slot_tab)
+    const float *__restrict__ partials, const float *__restrict__ gslots, int stamp)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
-    // Parameters and optimizer state first: these loads do not depend on the gather below, so
-    // they are in flight while its three dependent rounds (table, lengths, partials) complete.
+    // Parameters, optimizer state and the Gaussian's own partial-sum slots depend on nothing but
+    // g: one round trip for all of them.
     const size_t g2 = 2 * (size_t)g, g3 = 3 * (size_t)g;
     const AdanSlot x0 = adan_load(T, 0, g2), x1 = adan_load(T, 0, g2 + 1);
     const AdanSlot c0 = adan_load(T, 1, RS ? g2 : g3), c1 = adan_load(T, 1, (RS ? g2 : g3) + 1);
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
                    f2 = adan_load(T, 3, g3 + 2);
     float acc[PART_STRIDE];
     gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
-                    tile_len, seg, C, partials, slot_tab, acc);
+                    tile_len, seg, C, partials, gslots, stamp, acc);
     const float t0 = tanhf(x0.p), t1 = tanhf(x1.p);
     // means = tanh(_xyz); xys = 0.5*(W,H)*means + ...
     const float gx0 = 0.5f * (float)W * acc[0] * (1.0f - t0 * t0);
@@ -198,11 +198,13 @@ int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_
     if (kind == 0)
         fit_tail_kernel<false><<<cdiv(N, 256), 256, 0, st>>>(
             Tn, h, xys, radii, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1,
-            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_slot_tab);
+            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_gslots,
+            (int)ws->generation);
     else
         fit_tail_kernel<true><<<cdiv(N, 256), 256, 0, st>>>(
             Tn, h, xys, radii, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1,
-            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_slot_tab);
+            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_gslots,
+            (int)ws->generation);
     return launch_status();
 }
 

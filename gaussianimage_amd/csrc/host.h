@@ -13,7 +13,7 @@ struct gi2d_workspace {
     int64_t part_slots = 0;
     float *d_partials = nullptr;  // [tiles][seg_cap][9] backward partial sums
     int64_t slot_cap = 0;
-    int *d_slot_tab = nullptr;  // [n][SLOT_TAB] list position of a Gaussian in its first tiles
+    float *d_gslots = nullptr;  // [n][GSLOTS][GSLOT_STRIDE] per-Gaussian partial sums + stamp
     DevStatus *d_status = nullptr;
     long long *h_status = nullptr;  // pinned: [0] max count, [1] generation, [2] overflow gen.
     long long *h_status_dev = nullptr;

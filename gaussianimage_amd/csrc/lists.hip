@@ -237,7 +237,7 @@ int gi2d_workspace_destroy(gi2d_workspace *ws)
     if (ws->d_len) (void)hipFree(ws->d_len);
     if (ws->d_seg) (void)hipFree(ws->d_seg);
     if (ws->d_partials) (void)hipFree(ws->d_partials);
-    if (ws->d_slot_tab) (void)hipFree(ws->d_slot_tab);
+    if (ws->d_gslots) (void)hipFree(ws->d_gslots);
     if (ws->d_status) (void)hipFree(ws->d_status);
     if (ws->h_status) (void)hipHostFree(ws->h_status);
     delete ws;

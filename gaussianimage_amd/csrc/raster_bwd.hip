@@ -12,8 +12,9 @@
 // round-robin over its four lanes, keeps the entry's nine partial sums in registers, adds the
 // four lanes with two DPP steps and writes the sums to the entry's own slot of a [slots][9]
 // slab -- no cross-lane tree, no atomics -- and notes the slot in a small per-Gaussian table.
-// Pass 2 (one lane per Gaussian): adds the Gaussian's slots in tile order; slots of the first
-// SLOT_TAB tiles come from the table, the rest by binary search (lists ascend in Gaussian id).
+// Pass 2 (one lane per Gaussian): adds the Gaussian's partial sums in tile order; those of the
+// first GSLOTS tiles of its box lie in the Gaussian's own slots, the rest are found by binary
+// search (lists ascend in Gaussian id).
 // ------------------------------------------------------------------------------------------
 
 // sum over the LPE (4, 8 or 16) neighbouring lanes of an entry's group, result in every lane
@@ -33,7 +34,8 @@ __device__ __forceinline__ void bwd_tile(
     const float4 *s_v, const float *__restrict__ xys, const int *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
-    const gi2d_conv &cv, int cull, float *__restrict__ partials, int *__restrict__ slot_tab)
+    const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
+    int stamp)
 {
     constexpr int EPB = 256 / LPE;  // entries per batch
     const int tid = threadIdx.x;
@@ -111,16 +113,23 @@ __device__ __forceinline__ void bwd_tile(
 #pragma unroll
         for (int k = 0; k < PART_STRIDE; ++k) acc[k] = group_sum<LPE>(acc[k]);
         if (e < n_raw && q == 0) {
-            float *dst = partials + (slot0 + e) * PART_STRIDE;
+            // index of this tile in the Gaussian's own (band-clipped) tile box: the first GSLOTS
+            // tiles write to the Gaussian's slots (with the stamp), the others to the tile's slab
+            TileBox box = tile_box(gx, gy, (float)rad, tiles_x, tiles_y);
+            const int by0 = max(box.y0, row0);
+            const int kb = (ty - by0) * (box.x1 - box.x0) + (tx - box.x0);
+            if (rad > 0 && kb >= 0 && kb < GSLOTS) {
+                float2 *dst = reinterpret_cast<float2 *>(
+                    gslots + ((size_t)gid * GSLOTS + kb) * GSLOT_STRIDE);
+                dst[0] = make_float2(acc[0], acc[1]);
+                dst[1] = make_float2(acc[2], acc[3]);
+                dst[2] = make_float2(acc[4], acc[5]);
+                dst[3] = make_float2(acc[6], acc[7]);
+                dst[4] = make_float2(acc[8], __int_as_float(stamp));
+            } else {
+                float *dst = partials + (slot0 + e) * PART_STRIDE;
 #pragma unroll
-            for (int k = 0; k < PART_STRIDE; ++k) dst[k] = acc[k];
-            // where pass 2 finds this slot without searching: index of this tile in the
-            // Gaussian's own (band-clipped) tile box, first SLOT_TAB tiles only
-            if (rad > 0) {
-                TileBox box = tile_box(gx, gy, (float)rad, tiles_x, tiles_y);
-                const int by0 = max(box.y0, row0);
-                const int kb = (ty - by0) * (box.x1 - box.x0) + (tx - box.x0);
-                if (kb >= 0 && kb < SLOT_TAB) slot_tab[(size_t)gid * SLOT_TAB + kb] = e;
+                for (int k = 0; k < PART_STRIDE; ++k) dst[k] = acc[k];
             }
         }
     }
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
     int T, gi2d_conv cv, int cull, const float *__restrict__ v_out,
-    float *__restrict__ partials, int *__restrict__ slot_tab)
+    float *__restrict__ partials, float *__restrict__ gslots, int stamp)
 {
     __shared__ float4 s_v[256];
     __shared__ int s_first[64];
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
     // a short list gets more lanes per entry: its rectangles are walked in fewer steps
 #define GI2D_BWD_TILE(LPE)                                                                      \
     bwd_tile<LPE>(lst, s_first, n_raw, slot0, tx, ty, s_v, xys, radii, conics, colors, opacity, \
-                  H, W, tiles_x, tiles_y, row0, cv, cull, partials, slot_tab)
+                  H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots, stamp)
     if (n_raw <= 16) GI2D_BWD_TILE(16);
     else if (n_raw <= 32) GI2D_BWD_TILE(8);
     else GI2D_BWD_TILE(4);
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
 __global__ __launch_bounds__(256) void gather_grads_kernel(
     const float *__restrict__ xys, const int *__restrict__ radii, int N, int tiles_x, int tiles_y,
     int row0, int row1, const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
-    const float *__restrict__ partials, const int *__restrict__ slot_tab,
+    const float *__restrict__ partials, const float *__restrict__ gslots, int stamp,
     float *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_colors,
     float *__restrict__ v_opacity)
 {
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(
     if (g >= N) return;
     float acc[PART_STRIDE];
     gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
-                    tile_len, seg, C, partials, slot_tab, acc);
+                    tile_len, seg, C, partials, gslots, stamp, acc);
     v_xy[2 * g] = acc[0];
     v_xy[2 * g + 1] = acc[1];
     v_conic[3 * g] = acc[2];
@@ -214,11 +223,12 @@ int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
     }
     if (ws->slot_cap < N) {
         HIP_TRY(hipDeviceSynchronize());
-        if (ws->d_slot_tab) (void)hipFree(ws->d_slot_tab);
-        ws->d_slot_tab = nullptr;
+        if (ws->d_gslots) (void)hipFree(ws->d_gslots);
+        ws->d_gslots = nullptr;
         ws->slot_cap = 0;
-        HIP_TRY(hipMalloc(&ws->d_slot_tab, sizeof(int) * SLOT_TAB * (size_t)N));
-        HIP_TRY(hipMemset(ws->d_slot_tab, 0, sizeof(int) * SLOT_TAB * (size_t)N));
+        const size_t bytes = sizeof(float) * GSLOTS * GSLOT_STRIDE * (size_t)N;
+        HIP_TRY(hipMalloc(&ws->d_gslots, bytes));
+        HIP_TRY(hipMemset(ws->d_gslots, 0, bytes));  // stamp 0 = never written (stamps are >= 1)
         ws->slot_cap = N;
     }
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
@@ -226,7 +236,7 @@ int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
         rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(
             ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, colors, opacity, H, W,
             ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull, v_out,
-            ws->d_partials, ws->d_slot_tab);
+            ws->d_partials, ws->d_gslots, (int)ws->generation);
         rc = launch_status();
     }
     return rc;
@@ -253,7 +263,8 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
     if (rc != GI2D_OK) return rc;
     gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(
         xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, ws->d_len, ws->d_seg,
-        ws->seg_cap, ws->d_partials, ws->d_slot_tab, v_xys, v_conics, v_colors, v_opacity);
+        ws->seg_cap, ws->d_partials, ws->d_gslots, (int)ws->generation, v_xys, v_conics, v_colors,
+        v_opacity);
     return launch_status();
 }
 
