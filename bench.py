@@ -327,8 +327,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-concurrent", action="store_true",
-                    help="skip the multi-stream extras (their overlapping kernels blur a "
-                         "profiler's per-kernel durations)")
+                    help="skip the multi-stream extras and the 4K point (overlapping kernels and "
+                         "a second workload blur a profiler's per-kernel averages)")
     ap.add_argument("--raster-ppl", type=int, default=0, choices=[0, 1, 2, 4],
                     help="pixels per lane of the forward rasteriser (0 = the library's choice)")
     args = ap.parse_args()
@@ -444,7 +444,7 @@ def main():
         if not args.no_concurrent:
             ex.update(bench_concurrent(args.workload, inputs, device, max(args.steps, 200)))
         ex.update(bench_model_loops(args.workload, device, k))
-        if args.workload == "kodak30k":
+        if args.workload == "kodak30k" and not args.no_concurrent:
             # the one-GPU point of the tile-row scaling series (3840x2160 / 200k Gaussians)
             big = FramePipeline(*[WORKLOADS["uhd200k"][i] for i in (2, 0, 1)],
                                 kind=WORKLOADS["uhd200k"][3], device=device)
