@@ -36,11 +36,19 @@ def get_conventions():
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else ctypes.c_void_p(0)
+    """Device address of a tensor for a ``void*`` parameter (None / empty -> NULL)."""
+    return t.data_ptr() if t is not None and t.numel() else None
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """The current HIP stream of ``device`` as a ``void*`` value."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx) or None
+    return torch.cuda.current_stream(device).cuda_stream or None
 
 
 def _need_cuda(name, *tensors):
@@ -52,7 +60,11 @@ def _need_cuda(name, *tensors):
 
 
 def _f32c(t):
-    return t.detach().to(torch.float32).contiguous()
+    """``t`` as a detached contiguous float32 tensor (itself when it already is one)."""
+    t = t.detach()
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t
+    return t.to(torch.float32).contiguous()
 
 
 class Workspace:
