@@ -26,6 +26,7 @@ BIN_NOGROW = 4
 
 OPT_CULL = 1
 OPT_RASTER_PPL = 2
+OPT_DROP_PENDING = 3
 
 BLOCK = 16
 MAX_COLOR_SETS = 3  # GI2D_MAX_COLOR_SETS
@@ -84,6 +85,9 @@ SIGNATURES = {
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_render_rs_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gi2d_fit_backward_step_chain": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp,
+                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          ctypes.POINTER(AdanHyper), _vp]),
     "gi2d_decode_params": (_i, [_i, ctypes.POINTER(Codec), _i, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_decode_render": (_i, [_vp, _i, ctypes.POINTER(Codec), _vp, _vp, _i, _i, _i, _convp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

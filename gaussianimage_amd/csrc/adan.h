@@ -73,8 +73,9 @@ __device__ __forceinline__ AdanSlot adan_load(const AdanTensors &T, int k, size_
     return s;
 }
 
-__device__ __forceinline__ void adan_apply(const AdanScalars &h, const AdanTensors &T, int k,
-                                           size_t i, AdanSlot s, float g)
+// Updates the element in memory and returns the new parameter value.
+__device__ __forceinline__ float adan_apply(const AdanScalars &h, const AdanTensors &T, int k,
+                                            size_t i, AdanSlot s, float g)
 {
     adan_element(h, g, s.p, s.m, s.n, s.d, s.prev);
     T.p[k][i] = s.p;
@@ -82,4 +83,5 @@ __device__ __forceinline__ void adan_apply(const AdanScalars &h, const AdanTenso
     T.n[k][i] = s.n;
     T.d[k][i] = s.d;
     T.prev[k][i] = s.prev;
+    return s.p;
 }

@@ -12,14 +12,30 @@
 // Operation order per element follows /root/reference/optimizer.py:319-362.
 // ------------------------------------------------------------------------------------------
 
-template <bool RS>
+// What the chained variant needs to project the updated parameters and fill the next
+// iteration's tile lists (into the workspace's second list set).
+struct ChainArgs {
+    float center_bias;
+    float *depths, *conics;
+    int *num_tiles_hit;
+    int *next_count, *next_seg;
+    const DevStatus *status;
+    volatile long long *h_status;
+    long long generation;
+};
+
+// CHAIN = true: having updated Gaussian g's parameters, the lane goes straight on to the next
+// iteration's projection of g (model activations included) -- outputs overwritten in place,
+// tile lists of the next frame filled -- so the next iteration needs no projection launch.
+template <bool RS, bool CHAIN>
 __global__ __launch_bounds__(256) void fit_tail_kernel(
-    AdanTensors T, AdanScalars h, const float *__restrict__ xys, const int *__restrict__ radii,
-    int N, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
-    const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
-    const float *__restrict__ partials, const float *__restrict__ gslots, int stamp)
+    AdanTensors T, AdanScalars h, float *xys, int *radii, int N, int H, int W, int tiles_x,
+    int tiles_y, int row0, int row1, const int *__restrict__ tile_len,
+    const int *__restrict__ seg, int C, const float *__restrict__ partials,
+    const float *__restrict__ gslots, int stamp, ChainArgs ch)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (CHAIN && g == 0) publish_status(ch.status, ch.h_status, ch.generation);
     if (g >= N) return;
     // Parameters, optimizer state and the Gaussian's own partial-sum slots depend on nothing but
     // g: one round trip for all of them.
@@ -74,14 +90,38 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
             vm1 = gx1;
         }
     }
-    adan_apply(h, T, 0, g2, x0, vm0);
-    adan_apply(h, T, 0, g2 + 1, x1, vm1);
-    adan_apply(h, T, 1, RS ? g2 : g3, c0, o0);
-    adan_apply(h, T, 1, (RS ? g2 : g3) + 1, c1, o1);
-    adan_apply(h, T, RS ? 2 : 1, RS ? (size_t)g : g3 + 2, c2, o2);
+    const float nx0 = adan_apply(h, T, 0, g2, x0, vm0);
+    const float nx1 = adan_apply(h, T, 0, g2 + 1, x1, vm1);
+    const float nc0 = adan_apply(h, T, 1, RS ? g2 : g3, c0, o0);
+    const float nc1 = adan_apply(h, T, 1, (RS ? g2 : g3) + 1, c1, o1);
+    const float nc2 = adan_apply(h, T, RS ? 2 : 1, RS ? (size_t)g : g3 + 2, c2, o2);
     adan_apply(h, T, 3, g3, f0, acc[5]);
     adan_apply(h, T, 3, g3 + 1, f1, acc[6]);
     adan_apply(h, T, 3, g3 + 2, f2, acc[7]);
+    if (CHAIN) {
+        // the next iteration's projection of this Gaussian: the same arithmetic as
+        // project_*_fwd_kernel<RAW = true> on the parameters just written
+        const float mx = tanhf(nx0), my = tanhf(nx1);
+        float sxx, sxy, syy;
+        if (!RS) {
+            const float l11 = nc0 + 0.5f, l21 = nc1, l22 = nc2 + 0.5f;
+            sxx = l11 * l11;
+            sxy = l11 * l21;
+            syy = l21 * l21 + l22 * l22;
+        } else {
+            const float s1 = fabsf(nc0 + 0.5f), s2 = fabsf(nc1 + 0.5f);
+            const float theta = (1.0f / (1.0f + expf(-nc2))) * 2.0f * 3.14159274f;
+            float s, c;
+            sincosf(theta, &s, &c);
+            const float q1 = s1 * s1, q2 = s2 * s2;
+            sxx = c * c * q1 + s * s * q2;
+            sxy = c * s * (q1 - q2);
+            syy = s * s * q1 + c * c * q2;
+        }
+        project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, ch.center_bias, xys,
+                     ch.depths, radii, ch.conics, ch.num_tiles_hit, ch.next_count, ch.next_seg, C,
+                     row0, row1);
+    }
 }
 
 __global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScalars h,
@@ -146,9 +186,16 @@ int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float
 {
     if (!ws || (kind != 0 && kind != 1) || !gt_chw) return GI2D_E_INVALID;
     const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
-    int rc = project_impl(kind, true, xyz, cov_a, cov_b, N, H, W, tiles_x, tiles_y, conv, xys,
+    int rc = GI2D_OK;
+    // a chained step has already projected these parameters into these outputs and filled the lists
+    const bool chained = ws->chain_pending && ws->prefilled && ws->chain_kind == kind &&
+                         ws->chain_xys == (const void *)xys && ws->pre_n == N &&
+                         ws->pre_tx == tiles_x && ws->pre_ty == tiles_y;
+    if (!chained) {
+        rc = project_impl(kind, true, xyz, cov_a, cov_b, N, H, W, tiles_x, tiles_y, conv, xys,
                           depths, radii, conics, num_tiles_hit, ws, stream);
-    if (rc != GI2D_OK) return rc;
+        if (rc != GI2D_OK) return rc;
+    }
     rc = gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
     if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
     const int late = rc;
@@ -157,12 +204,20 @@ int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float
     return rc != GI2D_OK ? rc : late;
 }
 
-int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
-                           float *features, const float *opacity, int N, int H, int W,
-                           const gi2d_conv *conv, const float *xys, const int *radii,
-                           const float *conics, const float *v_image, float *const *exp_avg,
-                           float *const *exp_avg_sq, float *const *exp_avg_diff,
-                           float *const *neg_pre_grad, const gi2d_adan_hyper *hyper, void *stream)
+// chain != NULL: the projection outputs to overwrite for the next iteration (see
+// gi2d_fit_backward_step_chain); the const inputs xys / radii / conics then alias them.
+struct ChainOutputs {
+    float *xys, *depths, *conics;
+    int *radii, *num_tiles_hit;
+};
+
+static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                             float *features, const float *opacity, int N, int H, int W,
+                             const gi2d_conv *conv, const float *xys, const int *radii,
+                             const float *conics, const float *v_image, float *const *exp_avg,
+                             float *const *exp_avg_sq, float *const *exp_avg_diff,
+                             float *const *neg_pre_grad, const gi2d_adan_hyper *hyper,
+                             void *stream, const ChainOutputs *chain)
 {
     if (kind != 0 && kind != 1) return GI2D_E_INVALID;
     int rc = check_raster_args(ws, N, H, W, conv);
@@ -195,17 +250,66 @@ int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_
     hipStream_t st = (hipStream_t)stream;
     rc = raster_bwd_pass1(ws, xys, radii, conics, features, opacity, N, H, W, conv, v_image, st);
     if (rc != GI2D_OK) return rc;
-    if (kind == 0)
-        fit_tail_kernel<false><<<cdiv(N, 256), 256, 0, st>>>(
-            Tn, h, xys, radii, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1,
-            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_gslots,
-            (int)ws->generation);
-    else
-        fit_tail_kernel<true><<<cdiv(N, 256), 256, 0, st>>>(
-            Tn, h, xys, radii, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1,
-            ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_gslots,
-            (int)ws->generation);
-    return launch_status();
+    const bool chained = chain != nullptr && begin_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y);
+    ChainArgs ch = ChainArgs();
+    if (chained) {
+        ch.center_bias = conv->center_bias;
+        ch.depths = chain->depths;
+        ch.conics = chain->conics;
+        ch.num_tiles_hit = chain->num_tiles_hit;
+        ch.next_count = ws->alt_count;
+        ch.next_seg = ws->alt_seg;
+        ch.status = ws->d_status;
+        ch.h_status = ws->h_status_dev;
+        ch.generation = ws->generation;
+    }
+    // (the kernel reads xys / radii of the current frame and, chained, overwrites them)
+    float *xys_io = chained ? chain->xys : const_cast<float *>(xys);
+    int *radii_io = chained ? chain->radii : const_cast<int *>(radii);
+#define GI2D_TAIL_ARGS Tn, h, xys_io, radii_io, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, \
+                       ws->bin_row1, ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials,          \
+                       ws->d_gslots, (int)ws->generation, ch
+    // one wave per workgroup when the lanes also issue the list-filling atomics, so that the
+    // launch spreads over every CU (as in the projection kernels)
+    const int threads = chained ? PG_THREADS : 256;
+    const dim3 grid(cdiv(N, threads)), block(threads);
+    if (kind == 0 && chained) fit_tail_kernel<false, true><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
+    else if (kind == 0) fit_tail_kernel<false, false><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
+    else if (chained) fit_tail_kernel<true, true><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
+    else fit_tail_kernel<true, false><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
+#undef GI2D_TAIL_ARGS
+    rc = launch_status();
+    if (rc == GI2D_OK && chained)
+        commit_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y, kind, chain->xys);
+    return rc;
+}
+
+int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                           float *features, const float *opacity, int N, int H, int W,
+                           const gi2d_conv *conv, const float *xys, const int *radii,
+                           const float *conics, const float *v_image, float *const *exp_avg,
+                           float *const *exp_avg_sq, float *const *exp_avg_diff,
+                           float *const *neg_pre_grad, const gi2d_adan_hyper *hyper, void *stream)
+{
+    return fit_backward_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
+                             radii, conics, v_image, exp_avg, exp_avg_sq, exp_avg_diff,
+                             neg_pre_grad, hyper, stream, nullptr);
+}
+
+int gi2d_fit_backward_step_chain(gi2d_workspace *ws, int kind, float *xyz, float *cov_a,
+                                 float *cov_b, float *features, const float *opacity, int N, int H,
+                                 int W, const gi2d_conv *conv, float *xys, float *depths,
+                                 int *radii, float *conics, int *num_tiles_hit,
+                                 const float *v_image, float *const *exp_avg,
+                                 float *const *exp_avg_sq, float *const *exp_avg_diff,
+                                 float *const *neg_pre_grad, const gi2d_adan_hyper *hyper,
+                                 void *stream)
+{
+    if (!xys || !depths || !radii || !conics || !num_tiles_hit) return GI2D_E_INVALID;
+    const ChainOutputs chain = {xys, depths, conics, radii, num_tiles_hit};
+    return fit_backward_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
+                             radii, conics, v_image, exp_avg, exp_avg_sq, exp_avg_diff,
+                             neg_pre_grad, hyper, stream, &chain);
 }
 
 int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,

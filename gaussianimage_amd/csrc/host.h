@@ -30,6 +30,12 @@ struct gi2d_workspace {
     int cull = 1;
     int raster_ppl = 0;  // 0 = choose by tile count
     int min_seg_cap = 64;
+    // Second list set (same tiles_cap x seg_cap): the fitting tail fills it with the NEXT
+    // iteration's lists while it still reads the current ones; the sets then swap roles.
+    int *alt_count = nullptr, *alt_len = nullptr, *alt_seg = nullptr;
+    bool chain_pending = false;      // the lists were prefilled by a chained fitting step ...
+    const void *chain_xys = nullptr;  // ... whose projection outputs live here
+    int chain_kind = -1;
 };
 
 #define HIP_TRY(expr)                                \
@@ -81,6 +87,9 @@ int wanted_cap(const gi2d_workspace *ws, long long seen);
 int zero_counters(gi2d_workspace *ws, hipStream_t st);
 int finalize_lists(gi2d_workspace *ws, hipStream_t st);
 int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream_t st);
+bool begin_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y);
+void commit_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int kind,
+                          const void *xys);
 
 // project.hip
 int project_impl(int kind, bool raw, const float *means, const float *cov_a, const float *cov_b,

@@ -76,6 +76,15 @@ __global__ __launch_bounds__(WAVE) void compact_lists_kernel(const int *__restri
 // host side
 // ------------------------------------------------------------------------------------------
 
+static void free_alt_lists(gi2d_workspace *ws)
+{
+    if (ws->alt_count) (void)hipFree(ws->alt_count);
+    if (ws->alt_len) (void)hipFree(ws->alt_len);
+    if (ws->alt_seg) (void)hipFree(ws->alt_seg);
+    ws->alt_count = ws->alt_len = ws->alt_seg = nullptr;
+    ws->chain_pending = false;
+}
+
 // (Re)allocates the per-tile arrays for T tiles of C ids each; the device is current.
 // Contents are lost: callers re-bin afterwards.
 int ensure_lists(gi2d_workspace *ws, int T, int C)
@@ -89,6 +98,7 @@ int ensure_lists(gi2d_workspace *ws, int T, int C)
     if (ws->d_len) (void)hipFree(ws->d_len);
     if (ws->d_seg) (void)hipFree(ws->d_seg);
     if (ws->d_partials) (void)hipFree(ws->d_partials);
+    free_alt_lists(ws);
     ws->d_count = ws->d_len = ws->d_seg = nullptr;
     ws->d_partials = nullptr;
     ws->part_slots = 0;
@@ -156,6 +166,7 @@ int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream
     const int r0 = min(ws->row0, tiles_y), r1 = min(ws->row1, tiles_y);
     const int T = (r1 - r0) * tiles_x;
     ws->prefilled = false;
+    ws->chain_pending = false;  // a new projection replaces whatever a chained step prepared
     if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1)) return GI2D_OK;
     int rc = ensure_lists(ws, max(1, T), wanted_cap(ws, ws->h_status[0]));
     if (rc != GI2D_OK) return rc;
@@ -174,6 +185,56 @@ int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream
     ws->pre_r0 = r0;
     ws->pre_r1 = r1;
     return GI2D_OK;
+}
+
+// The fitting tail wants to fill the NEXT iteration's lists while the current ones are still
+// being read.  Possible when the current lists are finalised and valid, the shape is unchanged
+// and no capacity growth is due (a growth reallocates, which would lose the current lists: the
+// next projection does it instead).  Makes sure the second list set exists; the device is current.
+bool begin_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y)
+{
+    const int r0 = min(ws->row0, tiles_y), r1 = min(ws->row1, tiles_y);
+    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1)) return false;
+    if (ws->counters_dirty || ws->lists_raw || !ws->lists_valid || ws->seg_cap == 0) return false;
+    if (wanted_cap(ws, ws->h_status[0]) > ws->seg_cap) return false;
+    if (!ws->alt_count) {
+        const size_t T = (size_t)ws->tiles_cap, C = (size_t)ws->seg_cap;
+        bool ok = hipMalloc(&ws->alt_count, sizeof(int) * CNT_STRIDE * T) == hipSuccess &&
+                  hipMalloc(&ws->alt_len, sizeof(int) * T) == hipSuccess &&
+                  hipMalloc(&ws->alt_seg, sizeof(int) * T * C) == hipSuccess &&
+                  hipMemset(ws->alt_count, 0, sizeof(int) * CNT_STRIDE * T) == hipSuccess &&
+                  hipMemset(ws->alt_len, 0, sizeof(int) * T) == hipSuccess;
+        ok = ok && hipDeviceSynchronize() == hipSuccess;  // the clears are done before any use
+        if (!ok) {
+            (void)hipGetLastError();
+            free_alt_lists(ws);
+            return false;
+        }
+    }
+    return true;
+}
+
+// The chained fill has been launched into the second set: it becomes the current one, in the
+// state a projection with list filling leaves behind (gi2d_bin_tiles(COUNTED) picks it up).
+void commit_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int kind,
+                          const void *xys)
+{
+    int *t;
+    t = ws->d_count, ws->d_count = ws->alt_count, ws->alt_count = t;
+    t = ws->d_len, ws->d_len = ws->alt_len, ws->alt_len = t;
+    t = ws->d_seg, ws->d_seg = ws->alt_seg, ws->alt_seg = t;
+    ws->counters_dirty = true;
+    ws->lists_raw = false;
+    ws->lists_valid = false;
+    ws->prefilled = true;
+    ws->pre_n = N;
+    ws->pre_tx = tiles_x;
+    ws->pre_ty = tiles_y;
+    ws->pre_r0 = min(ws->row0, tiles_y);
+    ws->pre_r1 = min(ws->row1, tiles_y);
+    ws->chain_pending = true;
+    ws->chain_kind = kind;
+    ws->chain_xys = xys;
 }
 
 extern "C" {
@@ -237,6 +298,7 @@ int gi2d_workspace_destroy(gi2d_workspace *ws)
     if (ws->d_len) (void)hipFree(ws->d_len);
     if (ws->d_seg) (void)hipFree(ws->d_seg);
     if (ws->d_partials) (void)hipFree(ws->d_partials);
+    free_alt_lists(ws);
     if (ws->d_gslots) (void)hipFree(ws->d_gslots);
     if (ws->d_status) (void)hipFree(ws->d_status);
     if (ws->h_status) (void)hipHostFree(ws->h_status);
@@ -262,6 +324,9 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
         case GI2D_OPT_RASTER_PPL:
             if (value != 0 && value != 1 && value != 2 && value != 4) return GI2D_E_INVALID;
             ws->raster_ppl = value;
+            return GI2D_OK;
+        case GI2D_OPT_DROP_PENDING:
+            ws->chain_pending = false;
             return GI2D_OK;
         default: return GI2D_E_INVALID;
     }
@@ -329,6 +394,7 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     bool prefilled = ws->prefilled && ws->pre_n == N && ws->pre_tx == tiles_x &&
                      ws->pre_ty == tiles_y && ws->pre_r0 == r0 && ws->pre_r1 == r1;
     ws->prefilled = false;
+    ws->chain_pending = false;
     if (!(flags & GI2D_BIN_COUNTED)) prefilled = false;
 
     if (!prefilled) {

@@ -1,7 +1,9 @@
 """Fused fitting loop: the reference's ``train_iter`` (forward, L2 loss, backward, Adan step --
 /root/reference/gaussianimage_cholesky.py:101-124, /root/reference/gaussianimage_rs.py:82-95)
-in four launches on the model's raw parameters, with no gradient tensors and no host
-synchronisation (``gi2d_fit_forward`` + ``gi2d_fit_backward_step``).
+in three launches on the model's raw parameters, with no gradient tensors and no host
+synchronisation (``gi2d_fit_forward`` + ``gi2d_fit_backward_step_chain``: rasterise with the loss
+epilogue; backward rasterisation; per Gaussian the gradient gather, the Adan update and, in the
+same lane, the projection of the updated parameters for the next iteration).
 
 This is an optional fast path beside the drop-in operators (which the reference's own model
 files keep using unchanged).  Parameter names and shapes are the reference model's
@@ -23,7 +25,7 @@ __all__ = ["FusedFitter"]
 class FusedFitter:
     def __init__(self, num_points, H, W, kind="cholesky", device="cuda:0", lr=1e-3,
                  betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0, no_prox=False,
-                 lr_step=20000, lr_gamma=0.5, params=None, keep_image=True):
+                 lr_step=20000, lr_gamma=0.5, params=None, keep_image=True, chain=True):
         if kind not in ("cholesky", "rs"):
             raise ValueError("kind must be 'cholesky' or 'rs'")
         self.kind, self.N, self.H, self.W = kind, int(num_points), int(H), int(W)
@@ -50,6 +52,11 @@ class FusedFitter:
                           ("exp_avg", "exp_avg_sq", "exp_avg_diff", "neg_pre_grad")}
                       for k, p in self.params.items()}
         self.step_count = 0
+        # chain: the step's last kernel also projects the updated parameters for the next
+        # iteration (one launch fewer).  The parameter tensors' versions tell whether anything
+        # but the fused step touched them in between; if so the next forward projects afresh.
+        self.chain = bool(chain)
+        self._versions = None
         self.overflowed_frames = 0  # iterations in which some tile list overflowed (see forward)
         self.ws = Workspace(d)
         self.conv = _lib.default_conv(**get_conventions())
@@ -82,6 +89,11 @@ class FusedFitter:
                           _ptr(p[3]), _ptr(self._opacity), self.N, self.H, self.W,
                           ctypes.byref(self.conv), _ptr(self.xys), _ptr(self.radii),
                           _ptr(self.conics), _ptr(self.v_image), *self._state_arrays)
+        self._chain_args = (self.ws.handle, self._kind, _ptr(p[0]), _ptr(p[1]), _ptr(p[2]),
+                            _ptr(p[3]), _ptr(self._opacity), self.N, self.H, self.W,
+                            ctypes.byref(self.conv), _ptr(self.xys), _ptr(self.depths),
+                            _ptr(self.radii), _ptr(self.conics), _ptr(self.num_tiles_hit),
+                            _ptr(self.v_image), *self._state_arrays)
         self._stream = _stream(self.device)
 
     @property
@@ -94,6 +106,12 @@ class FusedFitter:
         if gt_image.device != self.device or gt_image.dtype != torch.float32 or \
                 not gt_image.is_contiguous() or gt_image.numel() != 3 * self.H * self.W:
             raise ValueError("gt_image must be a contiguous float32 [1,3,H,W] tensor on the device")
+        if self._versions is not None:
+            if self._versions != self._param_versions():
+                # someone else wrote the parameters since the chained step projected them
+                check(lib.gi2d_workspace_set_option(self.ws.handle, _lib.OPT_DROP_PENDING, 1),
+                      "gi2d_workspace_set_option")
+            self._versions = None
         rc = lib.gi2d_fit_forward(*self._fwd_args, _ptr(gt_image), *self._fwd_tail, self._stream)
         if rc == _lib.GI2D_E_PREV_OVERFLOW:
             # An EARLIER iteration outgrew a tile list (Gaussians grow while fitting): its
@@ -112,8 +130,16 @@ class FusedFitter:
         b1, b2, b3 = self.betas
         hyper = _lib.AdanHyper(lr, b1, b2, b3, self.eps, self.weight_decay,
                                int(bool(self.no_prox)), self.step_count)
-        rc = lib.gi2d_fit_backward_step(*self._bwd_args, ctypes.byref(hyper), self._stream)
+        if self.chain:
+            rc = lib.gi2d_fit_backward_step_chain(*self._chain_args, ctypes.byref(hyper),
+                                                  self._stream)
+            self._versions = self._param_versions()
+        else:
+            rc = lib.gi2d_fit_backward_step(*self._bwd_args, ctypes.byref(hyper), self._stream)
         check(rc, "gi2d_fit_backward_step")
+
+    def _param_versions(self):
+        return tuple(p._version for p in self.params.values())
 
     def loss(self):
         """Mean squared error of the last forward (before that step's update)."""

@@ -72,6 +72,11 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
  * (workgroups of 4, 2 or 1 waves per tile), 0 (default) = chosen from the tile
  * count.  A tuning knob: every setting gives the same bits. */
 #define GI2D_OPT_RASTER_PPL 2
+/* GI2D_OPT_DROP_PENDING (any value): forget the projection a chained fitting
+ * step prepared for the next iteration (see gi2d_fit_backward_step_chain); the
+ * next gi2d_fit_forward projects again.  For callers that change the
+ * parameters themselves between two iterations. */
+#define GI2D_OPT_DROP_PENDING 3
 int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value);
 /* Tile-row band: binning and rasterisation cover tile rows [row_begin,row_end)
  * of the frame only (row_end is clipped to the frame); out_img / v_out then
@@ -188,7 +193,8 @@ int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
 
 /* Fused fitting iteration on the model's RAW parameters -- the caller's loop of
  * gaussianimage_cholesky.py:101-124 / gaussianimage_rs.py:82-95 (forward, L2
- * loss, backward, Adan step) in FOUR launches and no gradient tensors.
+ * loss, backward, Adan step) in FOUR launches (three with the chained step
+ * below) and no gradient tensors.
  * kind 0: _xyz[N,2], cov_a = _cholesky[N,3], cov_b unused, features[N,3];
  * kind 1: cov_a = _scaling[N,2], cov_b = _rotation[N,1].  The activations
  * (tanh, +cholesky_bound / |.+0.5|, sigmoid*2pi) are applied inside.
@@ -213,6 +219,25 @@ int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_
                            const float *conics, const float *v_image, float *const *exp_avg,
                            float *const *exp_avg_sq, float *const *exp_avg_diff,
                            float *const *neg_pre_grad, const gi2d_adan_hyper *hyper, void *stream);
+
+/* gi2d_fit_backward_step that also starts the NEXT iteration: the lane that
+ * has just updated a Gaussian's parameters projects them at once (activations
+ * included), overwrites xys / depths / radii / conics / num_tiles_hit with the
+ * next frame's values and fills the next frame's tile lists into a second list
+ * set of the workspace.  The next gi2d_fit_forward on the same workspace, kind
+ * and xys buffer then starts at the rasteriser: three launches per iteration.
+ * When the lists cannot be double-buffered at that moment (a capacity growth is
+ * due, a new shape) it behaves exactly like gi2d_fit_backward_step.  No
+ * counterpart in the reference (its loop re-projects in Python each
+ * iteration, gaussianimage_cholesky.py:101-103). */
+int gi2d_fit_backward_step_chain(gi2d_workspace *ws, int kind, float *xyz, float *cov_a,
+                                 float *cov_b, float *features, const float *opacity, int N, int H,
+                                 int W, const gi2d_conv *conv, float *xys, float *depths,
+                                 int *radii, float *conics, int *num_tiles_hit,
+                                 const float *v_image, float *const *exp_avg,
+                                 float *const *exp_avg_sq, float *const *exp_avg_diff,
+                                 float *const *neg_pre_grad, const gi2d_adan_hyper *hyper,
+                                 void *stream);
 
 /* ---- codec decode path ------------------------------------------------------
  * The coded attributes of one image, as compress_wo_ec() leaves them

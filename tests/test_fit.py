@@ -109,3 +109,36 @@ def test_growing_gaussians_do_not_stop_a_fit():
         assert torch.isfinite(p).all()
     fit.forward(gt)
     assert torch.isfinite(fit.v_image).all() and fit.loss() == fit.loss()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cholesky", "rs"])
+def test_chained_step_is_the_plain_step(kind):
+    """The step whose tail also projects the next iteration (3 launches) leaves, bit for bit, the
+    parameters, optimizer state and losses of the plain 4-launch step -- also across an outside
+    modification of the parameters between two iterations, which must not be missed."""
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N = 96, 112, 2500
+    gt = synth.target_image(H, W).to(DEV)
+    fits = []
+    for chain in (True, False):
+        torch.manual_seed(7)
+        fits.append(FusedFitter(N, H, W, kind=kind, device=DEV, chain=chain))
+    losses = [[], []]
+    for it in range(9):
+        for k, f in enumerate(fits):
+            if it == 5:  # someone edits the parameters behind the fitter's back
+                f.params["_xyz"].mul_(0.9)
+            f.step(gt)
+            losses[k].append(f.loss())
+    assert losses[0] == losses[1]
+    a, b = fits
+    for k in a.params:
+        assert torch.equal(a.params[k], b.params[k]), k
+        for s in a.state[k]:
+            assert torch.equal(a.state[k][s], b.state[k][s]), (k, s)
+    # the chained fitter's projection outputs are those of the parameters as they are now
+    b.forward(gt)
+    a.forward(gt)
+    assert torch.equal(a.xys, b.xys) and torch.equal(a.radii, b.radii)
+    assert torch.equal(a.conics, b.conics) and torch.equal(a.v_image, b.v_image)
