@@ -19,6 +19,7 @@ struct ChainArgs {
     float *depths, *conics;
     int *num_tiles_hit;
     int *next_count, *next_seg;
+    ListCull cull;
     const DevStatus *status;
     volatile long long *h_status;
     long long generation;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
         }
         project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, ch.center_bias, xys,
                      ch.depths, radii, ch.conics, ch.num_tiles_hit, ch.next_count, ch.next_seg, C,
-                     row0, row1);
+                     row0, row1, ch.cull);
     }
 }
 
@@ -193,7 +194,8 @@ int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float
                          ws->pre_tx == tiles_x && ws->pre_ty == tiles_y;
     if (!chained) {
         rc = project_impl(kind, true, xyz, cov_a, cov_b, N, H, W, tiles_x, tiles_y, conv, xys,
-                          depths, radii, conics, num_tiles_hit, ws, stream);
+                          depths, radii, conics, num_tiles_hit, ws, stream, nullptr, nullptr,
+                          opacity);
         if (rc != GI2D_OK) return rc;
     }
     rc = gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
@@ -259,6 +261,9 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
         ch.num_tiles_hit = chain->num_tiles_hit;
         ch.next_count = ws->alt_count;
         ch.next_seg = ws->alt_seg;
+        ch.cull.opacity = ws->cull ? opacity : nullptr;
+        ch.cull.alpha_min = conv->alpha_min;
+        ch.cull.pixel_offset = conv->pixel_offset;
         ch.status = ws->d_status;
         ch.h_status = ws->h_status_dev;
         ch.generation = ws->generation;

@@ -95,7 +95,8 @@ void commit_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, i
 int project_impl(int kind, bool raw, const float *means, const float *cov_a, const float *cov_b,
                  int N, int H, int W, int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
                  float *depths, int *radii, float *conics, int *num_tiles_hit, gi2d_workspace *ws,
-                 void *stream, const gi2d_codec *codec = nullptr, float *colors_out = nullptr);
+                 void *stream, const gi2d_codec *codec = nullptr, float *colors_out = nullptr,
+                 const float *cull_opacity = nullptr);
 
 // raster_fwd.hip
 int check_raster_args(gi2d_workspace *ws, int N, int H, int W, const gi2d_conv *conv);

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
     const float *__restrict__ means, const float *__restrict__ L, int N, int H, int W, int tiles_x,
     int tiles_y, float center_bias, float *__restrict__ xys, float *__restrict__ depths,
     int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count, int *seg, int C, int row0, int row1, const DevStatus *status,
+    int *tile_count, int *seg, int C, int row0, int row1, ListCull cull, const DevStatus *status,
     volatile long long *h_status, long long generation)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
     float sxy = l11 * l21;
     float syy = l21 * l21 + l22 * l22;
     project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths, radii,
-                 conics, num_tiles_hit, tile_count, seg, C, row0, row1);
+                 conics, num_tiles_hit, tile_count, seg, C, row0, row1, cull);
 }
 
 // RAW: means = tanh(_xyz), scales = |_scaling + 0.5|, rotation = sigmoid(_rotation) * 2 * pi
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     const float *__restrict__ rot, int N, int H, int W, int tiles_x, int tiles_y,
     float center_bias, float *__restrict__ xys, float *__restrict__ depths,
     int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count, int *seg, int C, int row0, int row1, const DevStatus *status,
+    int *tile_count, int *seg, int C, int row0, int row1, ListCull cull, const DevStatus *status,
     volatile long long *h_status, long long generation)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     float sxy = c * s * (q1 - q2);
     float syy = s * s * q1 + c * c * q2;
     project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths, radii,
-                 conics, num_tiles_hit, tile_count, seg, C, row0, row1);
+                 conics, num_tiles_hit, tile_count, seg, C, row0, row1, cull);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void project_decode_fwd_kernel(
     gi2d_codec cd, float *__restrict__ colors, int N, int H, int W, int tiles_x, int tiles_y,
     float center_bias, float *__restrict__ xys, float *__restrict__ depths,
     int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count, int *seg, int C, int row0, int row1, const DevStatus *status,
+    int *tile_count, int *seg, int C, int row0, int row1, ListCull cull, const DevStatus *status,
     volatile long long *h_status, long long generation)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void project_decode_fwd_kernel(
         syy = d.a1 * d.a1 + d.a2 * d.a2;
     }
     project_tail(g, d.mx, d.my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths,
-                 radii, conics, num_tiles_hit, tile_count, seg, C, row0, row1);
+                 radii, conics, num_tiles_hit, tile_count, seg, C, row0, row1, cull);
 }
 
 __global__ __launch_bounds__(256) void project_cholesky_bwd_kernel(
@@ -291,7 +291,7 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a,
                         const float *cov_b, int N, int H, int W, int tiles_x, int tiles_y,
                         const gi2d_conv *conv, float *xys, float *depths, int *radii,
                         float *conics, int *num_tiles_hit, gi2d_workspace *ws, void *stream,
-                        const gi2d_codec *codec, float *colors_out)
+                        const gi2d_codec *codec, float *colors_out, const float *cull_opacity)
 {
     if (codec) {
         int rcc = check_codec(kind, codec, N);
@@ -321,8 +321,12 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a,
     long long *hs = fill ? ws->h_status_dev : nullptr;
     const long long gen = fill ? ws->generation : 0;
     const dim3 grid(cdiv(N, PG_THREADS)), block(PG_THREADS);
+    // list culling needs the opacities the rasteriser will use, and can be switched off with the
+    // rasteriser's own culling (GI2D_OPT_CULL)
+    ListCull cull = {nullptr, conv->alpha_min, conv->pixel_offset};
+    if (fill && ws->cull) cull.opacity = cull_opacity;
 #define GI2D_PROJ_ARGS N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii, conics, \
-                       num_tiles_hit, cnt, seg, C, r0, r1, status, hs, gen
+                       num_tiles_hit, cnt, seg, C, r0, r1, cull, status, hs, gen
     if (codec) {
         if (kind == 0)
             project_decode_fwd_kernel<false><<<grid, block, 0, st>>>(*codec, colors_out, GI2D_PROJ_ARGS);

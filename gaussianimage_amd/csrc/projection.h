@@ -1,13 +1,22 @@
 // projection.h -- per-Gaussian device code shared by the projection kernels and the fused
 // fitting tail: outputs + tile-list filling, and the chain rule from conic to covariance.
 #pragma once
+#include "support.h"
 #include "tiles.h"
+
+// Optional culling of the LISTS (never of the outputs): with the rasteriser's opacities known,
+// a Gaussian enters only the tiles of its box that its support can touch.
+struct ListCull {
+    const float *opacity;  // [N]; nullptr = list every tile of the box
+    float alpha_min, pixel_offset;
+};
 
 __device__ __forceinline__ void project_tail(int g, float mx, float my, float sxx, float sxy,
                                              float syy, int H, int W, int tiles_x, int tiles_y,
                                              float center_bias, float *xys, float *depths,
                                              int *radii, float *conics, int *num_tiles_hit,
-                                             int *tile_count, int *seg, int C, int row0, int row1)
+                                             int *tile_count, int *seg, int C, int row0, int row1,
+                                             const ListCull &cull)
 {
     float ca = 0.f, cb = 0.f, cc = 0.f, radius = 0.f, cx = 0.f, cy = 0.f;
     int irad = 0, area = 0;
@@ -30,8 +39,12 @@ __device__ __forceinline__ void project_tail(int g, float mx, float my, float sx
     conics[3 * g + 1] = cb;
     conics[3 * g + 2] = cc;
     num_tiles_hit[g] = area;
-    if (tile_count != nullptr && irad > 0 && area > 0)
+    if (tile_count != nullptr && irad > 0 && area > 0) {
+        if (cull.opacity != nullptr)
+            cull_tile_box(box, cx, cy, ca, cb, cc, cull.opacity[g], cull.alpha_min,
+                          cull.pixel_offset);
         emit_tiles(g, box, row0, row1, tiles_x, tile_count, seg, C);
+    }
 }
 
 // dL/dSigma from dL/dconic: with C = Sigma^-1 and V = [[va, vb/2],[vb/2, vc]], G = -C V C;

@@ -410,8 +410,9 @@ int gi2d_render_cholesky_fwd(gi2d_workspace *ws, const float *means2d, const flo
 {
     if (!ws) return GI2D_E_INVALID;
     const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
-    int rc = gi2d_project_cholesky_fwd(means2d, L_elements, N, H, W, tiles_x, tiles_y, conv, xys,
-                                       depths, radii, conics, num_tiles_hit, ws, stream);
+    int rc = project_impl(0, false, means2d, L_elements, nullptr, N, H, W, tiles_x, tiles_y, conv,
+                          xys, depths, radii, conics, num_tiles_hit, ws, stream, nullptr, nullptr,
+                          opacity);
     if (rc != GI2D_OK) return rc;
     return render_tail(ws, N, H, W, tiles_x, tiles_y, conv, xys, radii, conics, colors, opacity,
                        background, out_img, raster_begin_event, raster_end_event, stream);
@@ -426,8 +427,9 @@ int gi2d_render_rs_fwd(gi2d_workspace *ws, const float *means2d, const float *sc
 {
     if (!ws) return GI2D_E_INVALID;
     const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
-    int rc = gi2d_project_rs_fwd(means2d, scales, rotation, N, H, W, tiles_x, tiles_y, conv, xys,
-                                 depths, radii, conics, num_tiles_hit, ws, stream);
+    int rc = project_impl(1, false, means2d, scales, rotation, N, H, W, tiles_x, tiles_y, conv, xys,
+                          depths, radii, conics, num_tiles_hit, ws, stream, nullptr, nullptr,
+                          opacity);
     if (rc != GI2D_OK) return rc;
     return render_tail(ws, N, H, W, tiles_x, tiles_y, conv, xys, radii, conics, colors, opacity,
                        background, out_img, raster_begin_event, raster_end_event, stream);
@@ -441,7 +443,8 @@ int gi2d_decode_render(gi2d_workspace *ws, int kind, const gi2d_codec *codec, co
     if (!ws || (!out_img && !render_chw)) return GI2D_E_INVALID;
     const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
     int rc = project_impl(kind, false, nullptr, nullptr, nullptr, N, H, W, tiles_x, tiles_y, conv,
-                          xys, depths, radii, conics, num_tiles_hit, ws, stream, codec, colors);
+                          xys, depths, radii, conics, num_tiles_hit, ws, stream, codec, colors,
+                          opacity);
     if (rc != GI2D_OK) return rc;
     return render_tail(ws, N, H, W, tiles_x, tiles_y, conv, xys, radii, conics, colors, opacity,
                        background, out_img, nullptr, nullptr, stream, render_chw);

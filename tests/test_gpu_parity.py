@@ -579,6 +579,9 @@ def test_pixels_per_lane_variants_give_the_same_bits(ops, oracle, H, W, N, seed,
     means, L, col, op = (t.to(DEV) for t in synth.cholesky_inputs(N, seed=seed, footprint=fp))
     op = (0.2 + 0.8 * torch.rand(N, 1, generator=torch.Generator().manual_seed(seed))).to(DEV)
     pipe = FramePipeline(N, H, W, device=DEV, workspace=ops.Workspace(DEV))
+    # (the very first frame of a shape sizes the lists from a plain binning of every box tile;
+    # from the second on the projection fills them, leaving out tiles the support cannot touch)
+    pipe.forward(means, L, None, col, op)
     results = {}
     for ppl in (1, 2, 4):
         pipe.ws.set_raster_ppl(ppl)
