@@ -690,3 +690,62 @@ def test_full_size_backward_properties(ops, oracle, H, W, N):
     assert torch.equal(gc_e[m], gc1[m]) and torch.equal(gc_o[~m], gc1[~m])
     assert not gc_e[~m].any() and not gx_e[~m].any()
     assert _maxrel(_np(gx_e + gx_o), _np(gx1)) <= 1e-5
+
+
+@pytest.mark.parametrize("kind", ["cholesky", "rs"])
+def test_fused_projection_lists_only_tiles_the_support_can_touch(ops, oracle, kind):
+    """With the opacities at hand the one-call frame leaves out (tile, Gaussian) pairs whose
+    support rectangle on that tile is empty: its lists are a subset of the reference lists
+    (every tile of the radius box), every omitted pair is one the oracle gives no contribution
+    on any pixel, image and gradients are unchanged, and with culling off the lists are the
+    reference lists again."""
+    from gaussianimage_amd.pipeline import FramePipeline
+    H, W, N = 112, 144, 3000
+    g = torch.Generator().manual_seed(4)
+    if kind == "cholesky":
+        means, a, col, _ = synth.cholesky_inputs(N, seed=9, footprint=1.5)
+        b = None
+    else:
+        means, a, b, col, _ = synth.rs_inputs(N, seed=9, footprint=1.5)
+    opa = torch.where(torch.rand(N, generator=g) > 0.3, torch.rand(N, generator=g),
+                      torch.zeros(N)).to(DEV)  # some low, some zero opacities
+    dev = [None if t is None else t.to(DEV).contiguous() for t in (means, a, b, col)]
+    pipe = FramePipeline(N, H, W, kind=kind, device=DEV, workspace=ops.Workspace(DEV))
+    pipe.forward(*dev, opa)                      # sizes the lists (plain binning)
+    img = pipe.forward(*dev, opa).clone()        # lists filled by the projection, culled
+    offs, ids = pipe.ws.bins()
+    r_offs, r_ids = oracle.bin_tiles(_np(pipe.xys), _np(pipe.radii), H, W)
+    assert int(offs[-1]) < int(r_offs[-1]) * 0.9
+    xys, conics = _np(pipe.xys), _np(pipe.conics)
+    op_np = _np(opa)
+    tiles_x = (W + 15) // 16
+    dropped = 0
+    for t in range(len(r_offs) - 1):
+        mine = set(ids[offs[t]:offs[t + 1]].tolist())
+        full = r_ids[r_offs[t]:r_offs[t + 1]]
+        assert mine <= set(full.tolist())
+        gone = np.array(sorted(set(full.tolist()) - mine), dtype=np.int64)
+        if len(gone) == 0:
+            continue
+        dropped += len(gone)
+        # alpha of every dropped Gaussian on every pixel of the tile, in float64
+        ty, tx = divmod(t, tiles_x)
+        ys, xs = np.mgrid[ty * 16:min(ty * 16 + 16, H), tx * 16:min(tx * 16 + 16, W)]
+        dx = xys[gone, 0][:, None, None] - xs[None]
+        dy = xys[gone, 1][:, None, None] - ys[None]
+        ca, cb, cc = (conics[gone, k].astype(np.float64)[:, None, None] for k in range(3))
+        sigma = 0.5 * (ca * dx * dx + cc * dy * dy) + cb * dx * dy
+        alpha = op_np[gone].astype(np.float64)[:, None, None] * np.exp(-sigma)
+        assert (alpha < 1.0 / 255.0).all()
+    assert dropped == int(r_offs[-1]) - int(offs[-1])
+    v = torch.randn(H, W, 3, generator=g).to(DEV)
+    grads = [t.clone() for t in pipe.backward(*dev, opa, v) if t is not None]
+    pipe.ws.set_cull(False)
+    img_full = pipe.forward(*dev, opa).clone()
+    offs2, ids2 = pipe.ws.bins()
+    assert np.array_equal(offs2.numpy(), r_offs) and np.array_equal(ids2.numpy(), r_ids)
+    assert torch.equal(img_full, img)
+    grads_full = [t for t in pipe.backward(*dev, opa, v) if t is not None]
+    for a_, b_ in zip(grads, grads_full):
+        assert _maxrel(_np(a_), _np(b_)) <= 2e-6
+    pipe.ws.set_cull(True)
