@@ -368,7 +368,9 @@ def main():
     if args.raster_ppl:
         pipe.ws.set_raster_ppl(args.raster_ppl)
     pipe.forward(*inputs)
-    I = pipe.intersections()
+    # intersections as the reference counts them: the sum of num_tiles_hit (every tile of the
+    # radius box), whatever part of them the lists actually hold after culling
+    I = int(pipe.num_tiles_hit.sum().item())
     P, T = H * W, pipe.tiles_x * pipe.tiles_y
 
     el, raster_ms, empty_bracket_ms = bench_forward(pipe, inputs, args.steps, args.warmup,
