@@ -51,6 +51,7 @@ __device__ __forceinline__ void bwd_tile(
         for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
         int gid = 0, rad = 0;
         float gx = 0.f, gy = 0.f;
+        bool touched = false;  // the entry's support reaches this tile
         if (e < n_raw) {
             gid = base == 0 ? s_first[e] : lst[e];  // (the first 64 ids are already here)
             gx = xys[2 * gid];
@@ -63,6 +64,7 @@ __device__ __forceinline__ void bwd_tile(
             if (cull) support_rect(gx, gy, a, b, c, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
             const int w = x1 - x0 + 1, h = y1 - y0 + 1;
             const int cnt = (w > 0 && h > 0) ? w * h : 0;
+            touched = cnt > 0;
             // The lanes of the group take the rectangle's pixels round-robin.  LPE / w and
             // q / w for w in 1..16 from the hardware reciprocal (exact here: the quotients'
             // fractional parts are multiples of 1/w, well clear of the 1-ulp error).
@@ -119,6 +121,9 @@ __device__ __forceinline__ void bwd_tile(
             const int by0 = max(box.y0, row0);
             const int kb = (ty - by0) * (box.x1 - box.x0) + (tx - box.x0);
             if (rad > 0 && kb >= 0 && kb < GSLOTS) {
+                // (an entry that cannot reach the tile leaves its slot's old stamp: pass 2
+                // then counts it as the zero it is)
+                if (!touched) continue;
                 float2 *dst = reinterpret_cast<float2 *>(
                     gslots + ((size_t)gid * GSLOTS + kb) * GSLOT_STRIDE);
                 dst[0] = make_float2(acc[0], acc[1]);
