@@ -749,3 +749,67 @@ def test_fused_projection_lists_only_tiles_the_support_can_touch(ops, oracle, ki
     for a_, b_ in zip(grads, grads_full):
         assert _maxrel(_np(a_), _np(b_)) <= 2e-6
     pipe.ws.set_cull(True)
+
+
+@pytest.fixture
+def other_conventions(ops):
+    """The other plausible reading of the operators the reference does not contain: pixel
+    centres at +0.5 with the matching -0.5 bias, the 0.999 alpha cap, background added."""
+    conv = dict(pixel_offset=0.5, center_bias=-0.5, alpha_cap=0.999, bg_weight=1.0)
+    before = ops.get_conventions()
+    ops.set_conventions(**conv)
+    yield conv
+    ops.set_conventions(**before)
+
+
+@pytest.mark.parametrize("kind", ["cholesky", "rs"])
+def test_runtime_conventions_reach_every_kernel(ops, oracle, other_conventions, kind):
+    """Projection, per-tile and per-list culling, forward and backward all follow the runtime
+    convention fields: operator path and one-call frame against the oracle run with the same
+    fields (alpha cap active: opacities up to 1.5)."""
+    from gaussianimage_amd.pipeline import FramePipeline
+    H, W, N = 90, 120, 1500
+    conv = oracle.default_conv(**other_conventions)
+    g = torch.Generator().manual_seed(12)
+    if kind == "cholesky":
+        means, a, col, _ = synth.cholesky_inputs(N, seed=6, footprint=2.0)
+        b = None
+    else:
+        means, a, b, col, _ = synth.rs_inputs(N, seed=6, footprint=2.0)
+    opa = (1.5 * torch.rand(N, 1, generator=g))
+    bg = torch.tensor([0.2, 0.5, 0.7])
+    tb = oracle.tile_bounds(H, W)
+    dev = [None if t is None else t.to(DEV) for t in (means, a, b)]
+    if kind == "cholesky":
+        proj = ops.project_gaussians_2d(dev[0], dev[1], H, W, tb)
+        r_proj = oracle.project_cholesky_fwd(means.numpy(), a.numpy(), H, W, conv)
+        assert np.array_equal(_np(proj[0]), r_proj[0]) and np.array_equal(_np(proj[2]), r_proj[2])
+    else:
+        proj = ops.project_gaussians_2d_scale_rot(dev[0], dev[1], dev[2], H, W, tb)
+    xys, depths, radii, conics, nth = proj
+    leaves = [xys.detach().clone().requires_grad_(True),
+              conics.detach().clone().requires_grad_(True), col.to(DEV).requires_grad_(True),
+              opa.to(DEV).requires_grad_(True)]
+    img = ops.rasterize_gaussians_sum(leaves[0], depths, radii, leaves[1], nth, leaves[2],
+                                      leaves[3], H, W, 16, 16, background=bg.to(DEV))
+    v_out = torch.randn(H, W, 3, generator=g)
+    (img * v_out.to(DEV)).sum().backward()
+    offs, ids = oracle.bin_tiles(_np(xys), _np(radii), H, W)
+    ref, margin = oracle.rasterize_sum_fwd(_np(xys), _np(conics), col.numpy(), opa.numpy(), H, W,
+                                           offs, ids, background=bg.numpy(), conv=conv,
+                                           want_margin=True)
+    ok = margin > 1e-4
+    assert ok.mean() > 0.99
+    assert np.abs(_np(img) - ref)[ok].max() <= IMG_ATOL * max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(ref - bg.numpy()).max()) > 0.1          # the Gaussians are there ...
+    assert np.abs(_np(img)[0, 0] - ref[0, 0]).max() <= IMG_ATOL  # ... on top of the background
+    rg = oracle.rasterize_sum_bwd(_np(xys), _np(conics), col.numpy(), opa.numpy(), H, W, offs,
+                                  ids, v_out.numpy(), conv=conv)
+    for name, leaf, r in zip(("xys", "conics", "colors", "opacity"), leaves, rg):
+        assert _maxrel(_np(leaf.grad), r.reshape(leaf.shape)) <= GRAD_RTOL, name
+    # the one-call frame (lists culled with the same pixel offset) gives the operators' bits
+    pipe = FramePipeline(N, H, W, kind=kind, device=DEV, workspace=ops.Workspace(DEV))
+    pipe.background.copy_(bg)
+    args = (*dev, col.to(DEV), opa.to(DEV))
+    pipe.forward(*args)
+    assert torch.equal(pipe.forward(*args), img.detach())
