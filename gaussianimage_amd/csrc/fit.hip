@@ -181,7 +181,8 @@ extern "C" {
 
 int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
                      const float *cov_b, const float *features, const float *opacity,
-                     const float *gt_chw, int N, int H, int W, const gi2d_conv *conv, float *xys,
+                     const float *background, const float *gt_chw, int N, int H, int W,
+                     const gi2d_conv *conv, float *xys,
                      float *depths, int *radii, float *conics, int *num_tiles_hit, float *image,
                      float *v_image, float *loss_partials, void *stream)
 {
@@ -201,8 +202,8 @@ int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float
     rc = gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
     if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
     const int late = rc;
-    rc = raster_fwd_impl(ws, xys, conics, features, opacity, nullptr, N, H, W, conv, image, gt_chw,
-                         v_image, loss_partials, stream);
+    rc = raster_fwd_impl(ws, xys, conics, features, opacity, background, N, H, W, conv, image,
+                         gt_chw, v_image, loss_partials, stream);
     return rc != GI2D_OK ? rc : late;
 }
 

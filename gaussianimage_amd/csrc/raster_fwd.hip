@@ -48,7 +48,8 @@ template <bool FINALIZE, bool L2, int SETS, int PPL>
 __global__ __launch_bounds__(256 / PPL) void rasterize_sum_fwd_kernel(
     int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacity, float bg0, float bg1, float bg2, int H, int W, int tiles_x,
+    const float *__restrict__ opacity, const float *__restrict__ background, int H, int W,
+    int tiles_x,
     int row0, int T, gi2d_conv cv, int cull, DevStatus *status, long long generation,
     float *__restrict__ out, const float *__restrict__ gt, float *__restrict__ v_img,
     float *__restrict__ loss_part, ExtraSets extra)
@@ -199,12 +200,19 @@ __global__ __launch_bounds__(256 / PPL) void rasterize_sum_fwd_kernel(
             }
         }
     }
+    // the background is read on the device (three uniform loads) and only when it counts
+    float bg[3] = {0.f, 0.f, 0.f};
+    if (cv.bg_weight != 0.f) {
+        bg[0] = background[0];
+        bg[1] = background[1];
+        bg[2] = background[2];
+    }
     float sq[PPL];
 #pragma unroll
     for (int u = 0; u < PPL; ++u) {
-        float rr = r[u] + cv.bg_weight * bg0;
-        float gg = g[u] + cv.bg_weight * bg1;
-        float bb = b[u] + cv.bg_weight * bg2;
+        float rr = r[u] + cv.bg_weight * bg[0];
+        float gg = g[u] + cv.bg_weight * bg[1];
+        float bb = b[u] + cv.bg_weight * bg[2];
         if (n_raw > C) rr = gg = bb = __builtin_nanf("");  // overflowed segment: never silently wrong
         if (inside[u] && out != nullptr) {
             float *o = out + 3 * pix[u];
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256 / PPL) void rasterize_sum_fwd_kernel(
         }
     }
     if (NX && inside[0]) {
-        const float bgs[3] = {bg0, bg1, bg2};
+        const float *bgs = bg;
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
             float v = xacc[q] + cv.bg_weight * bgs[q % 3];
@@ -301,14 +309,8 @@ int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *conics,
         extra.chw_plane = (size_t)(min(H, ws->bin_row1 * GI2D_BLOCK) - y0) * (size_t)W;
     }
     if (conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
-    float bg[3] = {0.f, 0.f, 0.f};
-    if (conv->bg_weight != 0.0f) {
-        // three floats, needed as kernel arguments
-        HIP_TRY(hipMemcpyAsync(bg, background, sizeof(bg), hipMemcpyDefault, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
 #define GI2D_RASTER_ARGS ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, conics, colors, \
-                         opacity, bg[0], bg[1], bg[2], H, W, ws->tiles_x, ws->bin_row0, T, *conv, \
+                         opacity, background, H, W, ws->tiles_x, ws->bin_row0, T, *conv, \
                          ws->cull, ws->d_status, ws->generation, out_img, gt, v_img, loss_part, \
                          extra
     const bool fin = ws->lists_raw;

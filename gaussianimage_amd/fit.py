@@ -48,6 +48,7 @@ class FusedFitter:
         self.params = {k: params[k].detach().to(d, f32).contiguous().clone()
                        for k in names if k}
         self._opacity = torch.ones(N, 1, dtype=f32, device=d)
+        self.background = torch.ones(3, dtype=f32, device=d)  # gaussianimage_cholesky.py:38
         self.state = {k: {s: torch.zeros_like(p) for s in
                           ("exp_avg", "exp_avg_sq", "exp_avg_diff", "neg_pre_grad")}
                       for k, p in self.params.items()}
@@ -76,7 +77,7 @@ class FusedFitter:
         p = [self.params[k] if k else None for k in self.names]
         self._kind = 0 if self.kind == "cholesky" else 1
         self._fwd_args = (self.ws.handle, self._kind, _ptr(p[0]), _ptr(p[1]), _ptr(p[2]),
-                          _ptr(p[3]), _ptr(self._opacity))
+                          _ptr(p[3]), _ptr(self._opacity), _ptr(self.background))
         self._fwd_tail = (self.N, self.H, self.W, ctypes.byref(self.conv), _ptr(self.xys),
                           _ptr(self.depths), _ptr(self.radii), _ptr(self.conics),
                           _ptr(self.num_tiles_hit), _ptr(self.image), _ptr(self.v_image),

@@ -130,7 +130,9 @@ int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_
 /* rasterize_gaussians_sum(xys, depths, radii, conics, num_tiles_hit, colors,
  * opacity, H, W, BLOCK_H, BLOCK_W, background=..., return_alpha=False)
  * forward (gaussianimage_cholesky.py:81-82): out_img[H,W,3], using the lists
- * of the last gi2d_bin_tiles on ws.  colors[N,3], opacity[N], background[3]. */
+ * of the last gi2d_bin_tiles on ws.  colors[N,3], opacity[N]; background[3] is
+ * device memory like the rest and is read only when conv->bg_weight != 0 (it
+ * may be NULL otherwise). */
 int gi2d_rasterize_sum_fwd(gi2d_workspace *ws, const float *xys, const float *conics,
                            const float *colors, const float *opacity, const float *background,
                            int N, int H, int W, const gi2d_conv *conv, float *out_img,
@@ -202,7 +204,8 @@ int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
  * gi2d_fit_forward: projection + binning + rasterisation with the loss
  * epilogue: v_image[H,W,3] = d mse(clamp(img,0,1), gt) / d img, with gt stored
  * [3,H,W] like the model's gt_image; loss_partials[tiles] = per-tile sums of
- * squared errors (mse = sum / (3*H*W)); image[H,W,3] optional (NULL to skip).
+ * squared errors (mse = sum / (3*H*W)); image[H,W,3] optional (NULL to skip);
+ * background[3] as in gi2d_rasterize_sum_fwd (may be NULL while bg_weight is 0).
  * gi2d_fit_backward_step: backward rasterisation, then per Gaussian the sum of
  * its partials, the chain through projection and activations, and the Adan
  * update of its parameters in place.  State arrays hold 4 device pointers
@@ -210,9 +213,10 @@ int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,
  * kind 0. */
 int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
                      const float *cov_b, const float *features, const float *opacity,
-                     const float *gt_chw, int N, int H, int W, const gi2d_conv *conv, float *xys,
-                     float *depths, int *radii, float *conics, int *num_tiles_hit, float *image,
-                     float *v_image, float *loss_partials, void *stream);
+                     const float *background, const float *gt_chw, int N, int H, int W,
+                     const gi2d_conv *conv, float *xys, float *depths, int *radii, float *conics,
+                     int *num_tiles_hit, float *image, float *v_image, float *loss_partials,
+                     void *stream);
 int gi2d_fit_backward_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
                            float *features, const float *opacity, int N, int H, int W,
                            const gi2d_conv *conv, const float *xys, const int *radii,

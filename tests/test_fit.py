@@ -142,3 +142,32 @@ def test_chained_step_is_the_plain_step(kind):
     a.forward(gt)
     assert torch.equal(a.xys, b.xys) and torch.equal(a.radii, b.radii)
     assert torch.equal(a.conics, b.conics) and torch.equal(a.v_image, b.v_image)
+
+
+@pytest.mark.gpu
+def test_fused_fitter_under_the_alternative_conventions():
+    """The fitting path honours the runtime conventions too (pixel centres, alpha cap, added
+    background): its forward is the operator path's, bit for bit."""
+    from gaussianimage_amd import ops
+    from gaussianimage_amd.fit import FusedFitter
+    before = ops.get_conventions()
+    ops.set_conventions(pixel_offset=0.5, center_bias=-0.5, alpha_cap=0.999, bg_weight=0.25)
+    try:
+        H, W, N = 80, 96, 1200
+        torch.manual_seed(4)
+        fit = FusedFitter(N, H, W, kind="cholesky", device=DEV)
+        gt = synth.target_image(H, W).to(DEV)
+        fit.forward(gt)
+        tb = ((W + 15) // 16, (H + 15) // 16, 1)
+        proj = ops.project_gaussians_2d(torch.tanh(fit.params["_xyz"]),
+                                        fit.params["_cholesky"] + torch.tensor(
+                                            [0.5, 0.0, 0.5], device=DEV), H, W, tb)
+        img = ops.rasterize_gaussians_sum(*proj, fit.params["_features_dc"], fit._opacity, H, W,
+                                          16, 16, background=fit.background)
+        assert torch.equal(fit.image, img)
+        assert float(img.min()) >= 0.25  # the background is in
+        fit.step(gt)
+        fit.step(gt)
+        assert all(torch.isfinite(p).all() for p in fit.params.values())
+    finally:
+        ops.set_conventions(**before)
