@@ -64,9 +64,12 @@ void gi2d_default_conv(gi2d_conv *conv);
 int gi2d_workspace_create(int device, gi2d_workspace **out);
 int gi2d_workspace_destroy(gi2d_workspace *ws);
 int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int max_tiles);
-/* Options: GI2D_OPT_CULL (default 1) lets the backward skip pixels outside a
- * Gaussian's support rectangle; 0 evaluates every pixel of every listed tile
- * (same results, used by the tests to prove that). */
+/* Options: GI2D_OPT_CULL (default 1) lets the rasterisers skip pixels outside
+ * a Gaussian's support rectangle, and lets the entry points that know the
+ * opacities when they project (gi2d_render_*_fwd, gi2d_fit_*,
+ * gi2d_decode_render) list a Gaussian only in the tiles its support can touch;
+ * 0 lists every tile of the radius box and evaluates every pixel of every
+ * listed tile (same results, used by the tests to prove that). */
 #define GI2D_OPT_CULL 1
 /* GI2D_OPT_RASTER_PPL: pixels per lane of the forward rasteriser: 1, 2 or 4
  * (workgroups of 4, 2 or 1 waves per tile), 0 (default) = chosen from the tile
