@@ -24,10 +24,13 @@
 #define LOG2E 1.4426950408889634f
 #define PART_STRIDE 9  // backward partial sums per (tile, Gaussian): v_xy 2, v_conic 3, v_rgb 3, v_op 1
 // Backward pass 1 leaves the partial sums of a Gaussian's first GSLOTS tiles (row-major in its
-// tile box; boxes are mostly <= 2x2) in the Gaussian's OWN slots, GSLOT_STRIDE floats each: the 9
-// sums and the stamp of the binning they belong to.  Pass 2 reads them in one round, with no
-// look-up; further tiles go through the per-tile slab and a search.
-#define GSLOTS 4
+// tile box) in the Gaussian's OWN slots, GSLOT_STRIDE floats each: the 9 sums and the stamp of
+// the binning they belong to.  Pass 2 reads the first GSLOTS_EAGER of them before it knows
+// anything about the Gaussian (boxes at initialisation are mostly <= 2x2), the others once the
+// box is known (fitted Gaussians cover 3x3 .. 4x4 tiles) -- no look-up either way; only tiles
+// beyond GSLOTS go through the per-tile slab and a search in the tile's list.
+#define GSLOTS 16
+#define GSLOTS_EAGER 4
 #define GSLOT_STRIDE 10
 
 // ------------------------------------------------------------------------------------------

@@ -3,9 +3,10 @@
 #include "common.h"
 
 // Adds up Gaussian g's partial sums in the row-major order of its tile box.  The first GSLOTS
-// tiles come from the Gaussian's own slots, loaded before anything else is known about it (one
-// round trip); a slot counts only if its stamp is this binning's (an overflowed tile writes
-// none).  Larger boxes: the remaining tiles by binary search in the tile's sorted list.
+// tiles come from the Gaussian's own slots -- GSLOTS_EAGER of them loaded before anything else
+// is known about it (one round trip), the rest once the box is known; a slot counts only if its
+// stamp is this binning's (an overflowed or unreachable tile writes none).  Larger boxes: the
+// remaining tiles by binary search in the tile's sorted list.
 __device__ __forceinline__ void gather_partials(int g, int r, float cx, float cy, int tiles_x,
                                                 int tiles_y, int row0, int row1,
                                                 const int *__restrict__ tile_len,
@@ -14,10 +15,11 @@ __device__ __forceinline__ void gather_partials(int g, int r, float cx, float cy
                                                 const float *__restrict__ gslots, int stamp,
                                                 float acc[PART_STRIDE])
 {
-    float part[GSLOTS][GSLOT_STRIDE];
-    const float2 *src = reinterpret_cast<const float2 *>(gslots + (size_t)g * GSLOTS * GSLOT_STRIDE);
+    float part[GSLOTS_EAGER][GSLOT_STRIDE];
+    const float *mine = gslots + (size_t)g * GSLOTS * GSLOT_STRIDE;
+    const float2 *src = reinterpret_cast<const float2 *>(mine);
 #pragma unroll
-    for (int k = 0; k < GSLOTS * GSLOT_STRIDE / 2; ++k) {
+    for (int k = 0; k < GSLOTS_EAGER * GSLOT_STRIDE / 2; ++k) {
         const float2 v = src[k];
         part[(2 * k) / GSLOT_STRIDE][(2 * k) % GSLOT_STRIDE] = v.x;
         part[(2 * k + 1) / GSLOT_STRIDE][(2 * k + 1) % GSLOT_STRIDE] = v.y;
@@ -30,10 +32,37 @@ __device__ __forceinline__ void gather_partials(int g, int r, float cx, float cy
     const int w = box.x1 - box.x0;
     const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
 #pragma unroll
-    for (int k = 0; k < GSLOTS; ++k) {
+    for (int k = 0; k < GSLOTS_EAGER; ++k) {
         const bool live = k < cnt && __float_as_int(part[k][PART_STRIDE]) == stamp;
 #pragma unroll
         for (int u = 0; u < PART_STRIDE; ++u) acc[u] += live ? part[k][u] : 0.f;
+    }
+    // the Gaussian's further slots, four at a time: the loads of a group are independent of
+    // each other (one more round trip per group)
+    const int lim = min(cnt, GSLOTS);
+    for (int k0 = GSLOTS_EAGER; k0 < lim; k0 += 4) {
+        float2 v[4][GSLOT_STRIDE / 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = min(k0 + j, GSLOTS - 1);
+            const float2 *p = reinterpret_cast<const float2 *>(mine + k * GSLOT_STRIDE);
+#pragma unroll
+            for (int u = 0; u < GSLOT_STRIDE / 2; ++u) v[j][u] = p[u];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool live = k0 + j < lim && __float_as_int(v[j][4].y) == stamp;
+            // (a dead slot may hold anything, NaN included: select, do not multiply)
+            acc[0] += live ? v[j][0].x : 0.f;
+            acc[1] += live ? v[j][0].y : 0.f;
+            acc[2] += live ? v[j][1].x : 0.f;
+            acc[3] += live ? v[j][1].y : 0.f;
+            acc[4] += live ? v[j][2].x : 0.f;
+            acc[5] += live ? v[j][2].y : 0.f;
+            acc[6] += live ? v[j][3].x : 0.f;
+            acc[7] += live ? v[j][3].y : 0.f;
+            acc[8] += live ? v[j][4].x : 0.f;
+        }
     }
     for (int k = GSLOTS; k < cnt; ++k) {
         const int ty = y0 + k / w, tx = box.x0 + k % w;
