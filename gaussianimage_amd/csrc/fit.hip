@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
     AdanTensors T, AdanScalars h, float *xys, int *radii, int N, int H, int W, int tiles_x,
     int tiles_y, int row0, int row1, const int *__restrict__ tile_len,
     const int *__restrict__ seg, int C, const float *__restrict__ partials,
-    const float *__restrict__ gslots, int stamp, ChainArgs ch)
+    const float *__restrict__ gslots, size_t gslot_n, int stamp, ChainArgs ch)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (CHAIN && g == 0) publish_status(ch.status, ch.h_status, ch.generation);
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
                    f2 = adan_load(T, 3, g3 + 2);
     float acc[PART_STRIDE];
     gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
-                    tile_len, seg, C, partials, gslots, stamp, acc);
+                    tile_len, seg, C, partials, gslots, gslot_n, stamp, acc);
     const float t0 = tanhf(x0.p), t1 = tanhf(x1.p);
     // means = tanh(_xyz); xys = 0.5*(W,H)*means + ...
     const float gx0 = 0.5f * (float)W * acc[0] * (1.0f - t0 * t0);
@@ -274,7 +274,7 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
     int *radii_io = chained ? chain->radii : const_cast<int *>(radii);
 #define GI2D_TAIL_ARGS Tn, h, xys_io, radii_io, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, \
                        ws->bin_row1, ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials,          \
-                       ws->d_gslots, (int)ws->generation, ch
+                       ws->d_gslots, (size_t)ws->slot_cap, (int)ws->generation, ch
     // one wave per workgroup when the lanes also issue the list-filling atomics, so that the
     // launch spreads over every CU (as in the projection kernels)
     const int threads = chained ? PG_THREADS : 256;

@@ -12,17 +12,23 @@ __device__ __forceinline__ void gather_partials(int g, int r, float cx, float cy
                                                 const int *__restrict__ tile_len,
                                                 const int *__restrict__ seg, int C,
                                                 const float *__restrict__ partials,
-                                                const float *__restrict__ gslots, int stamp,
-                                                float acc[PART_STRIDE])
+                                                const float *__restrict__ gslots, size_t gslot_n,
+                                                int stamp, float acc[PART_STRIDE])
 {
+    // slot k of Gaussian g lies in plane k: [GSLOTS][gslot_n][GSLOT_STRIDE] (the planes of the
+    // tile indices that occur are the only memory touched)
     float part[GSLOTS_EAGER][GSLOT_STRIDE];
-    const float *mine = gslots + (size_t)g * GSLOTS * GSLOT_STRIDE;
-    const float2 *src = reinterpret_cast<const float2 *>(mine);
+    const float *mine = gslots + (size_t)g * GSLOT_STRIDE;
+    const size_t plane = gslot_n * GSLOT_STRIDE;
 #pragma unroll
-    for (int k = 0; k < GSLOTS_EAGER * GSLOT_STRIDE / 2; ++k) {
-        const float2 v = src[k];
-        part[(2 * k) / GSLOT_STRIDE][(2 * k) % GSLOT_STRIDE] = v.x;
-        part[(2 * k + 1) / GSLOT_STRIDE][(2 * k + 1) % GSLOT_STRIDE] = v.y;
+    for (int k = 0; k < GSLOTS_EAGER; ++k) {
+        const float2 *src = reinterpret_cast<const float2 *>(mine + k * plane);
+#pragma unroll
+        for (int u = 0; u < GSLOT_STRIDE / 2; ++u) {
+            const float2 v = src[u];
+            part[k][2 * u] = v.x;
+            part[k][2 * u + 1] = v.y;
+        }
     }
 #pragma unroll
     for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
@@ -45,7 +51,7 @@ __device__ __forceinline__ void gather_partials(int g, int r, float cx, float cy
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = min(k0 + j, GSLOTS - 1);
-            const float2 *p = reinterpret_cast<const float2 *>(mine + k * GSLOT_STRIDE);
+            const float2 *p = reinterpret_cast<const float2 *>(mine + k * plane);
 #pragma unroll
             for (int u = 0; u < GSLOT_STRIDE / 2; ++u) v[j][u] = p[u];
         }

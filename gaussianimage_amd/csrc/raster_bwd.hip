@@ -7,15 +7,47 @@
 // ------------------------------------------------------------------------------------------
 // rasterize_sum backward.
 //
-// Pass 1 (one workgroup per tile): a quad of lanes per list entry.  The quad walks only the
-// pixels of the entry's support rectangle (bounding box of the ellipse alpha >= alpha_min),
-// round-robin over its four lanes, keeps the entry's nine partial sums in registers, adds the
-// four lanes with two DPP steps and writes the sums to the entry's own slot of a [slots][9]
-// slab -- no cross-lane tree, no atomics -- and notes the slot in a small per-Gaussian table.
+// Pass 1 (one 256-lane workgroup per tile).  Short lists: a group of 4, 8 or 16 lanes per entry
+// walks the entry's support rectangle.  Long lists, per batch of up to 128 entries:
+//   A. one lane per entry stages the entry -- attributes and the support rectangle (bounding
+//      box of the ellipse alpha >= alpha_min) -- in LDS;
+//   B. the entries' pixel counts are cut into PIECES of at most `chunk` pixels, chunk chosen so
+//      that the batch makes about one piece per quad of lanes: the work of a big Gaussian is
+//      spread over several quads, a small one costs its quad only its own few pixels;
+//   C. a quad of lanes per piece walks the piece's pixels round-robin, nine partial sums in
+//      registers, adds its four lanes with two DPP steps and leaves the sums in LDS;
+//   D. one lane per entry adds the entry's pieces in order and writes the result to the
+//      Gaussian's own slot (or, beyond its first GSLOTS tiles, to the tile's slab).
+// No floating-point atomics: every sum has a fixed order, gradients are reproducible.
 // Pass 2 (one lane per Gaussian): adds the Gaussian's partial sums in tile order; those of the
 // first GSLOTS tiles of its box lie in the Gaussian's own slots, the rest are found by binary
 // search (lists ascend in Gaussian id).
 // ------------------------------------------------------------------------------------------
+
+#define BWD_BATCH 128                  // entries per batch of the work-piece path
+// Lists longer than this take the work-piece path.  Measured on MI355X: a 50k-Gaussian fit of a
+// ~1020x768 image spends 37 us per backward in its fitted regime with the threshold at 64, 30 us
+// at 32 or 16; frames at initialisation (small supports) are unaffected either way.
+#define BWD_PIECES_MIN_LIST 32
+#define BWD_QUADS 64                   // quads of lanes per workgroup
+#define BWD_MAX_PIECES (BWD_BATCH + BWD_QUADS)
+
+// inclusive prefix sum over the 256 lanes of the workgroup (s_w: 4 ints of LDS); total in `all`
+__device__ __forceinline__ int block_inclusive_scan(int v, int *s_w, int &all)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    __syncthreads();  // (s_w may still be read from an earlier scan)
+    if (lane == 63) s_w[wave] = v;
+    __syncthreads();
+    const int w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    all = w0 + w1 + w2 + w3;
+    return v + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+}
 
 // sum over the LPE (4, 8 or 16) neighbouring lanes of an entry's group, result in every lane
 template <int LPE>
@@ -35,7 +67,7 @@ __device__ __forceinline__ void bwd_tile(
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
     const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
-    int stamp)
+    size_t gslot_n, int stamp)
 {
     constexpr int EPB = 256 / LPE;  // entries per batch
     const int tid = threadIdx.x;
@@ -125,7 +157,7 @@ __device__ __forceinline__ void bwd_tile(
                 // then counts it as the zero it is)
                 if (!touched) continue;
                 float2 *dst = reinterpret_cast<float2 *>(
-                    gslots + ((size_t)gid * GSLOTS + kb) * GSLOT_STRIDE);
+                    gslots + ((size_t)kb * gslot_n + gid) * GSLOT_STRIDE);
                 dst[0] = make_float2(acc[0], acc[1]);
                 dst[1] = make_float2(acc[2], acc[3]);
                 dst[2] = make_float2(acc[4], acc[5]);
@@ -140,21 +172,194 @@ __device__ __forceinline__ void bwd_tile(
     }
 }
 
-__global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
+// The work-piece path (long lists): the batches of one tile.
+__device__ __forceinline__ void bwd_tile_pieces(
+    const int *__restrict__ lst, int gid_first, int n_raw, size_t slot0, int tx, int ty,
+    const float4 *s_v, float4 *s_r0, float4 *s_r1, float4 *s_r2, int *s_start, int *s_w,
+    float *s_piece, const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
+    const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
+    size_t gslot_n, int stamp)
+{
+    const int tid = threadIdx.x, q = tid & 3, quad = tid >> 2;
+    const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
+    const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
+    const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
+    const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
+    for (int base = 0; base < n_raw; base += BWD_BATCH) {
+        const int n = min(BWD_BATCH, n_raw - base);
+        // ---- A: stage entry `tid` ----------------------------------------------------------
+        int cnt = 0;
+        if (tid < n) {
+            const int gid = base == 0 ? gid_first : lst[base + tid];
+            const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
+            const float a = conics[3 * gid], b = conics[3 * gid + 1], c = conics[3 * gid + 2];
+            const float op = opacity[gid];
+            const int rad = radii[gid];
+            int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
+            if (cull) support_rect(gx, gy, a, b, c, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
+            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+            cnt = (w > 0 && h > 0) ? w * h : 0;
+            const int rect = cnt ? (x0 | (x1 << 8) | (y0 << 16) | (y1 << 24)) : 0;
+            s_r0[tid] = make_float4(gx, gy, a, b);
+            s_r1[tid] = make_float4(c, op, colors[3 * gid], colors[3 * gid + 1]);
+            s_r2[tid] = make_float4(colors[3 * gid + 2], __int_as_float(gid), __int_as_float(rad),
+                                    __int_as_float(rect));
+        }
+        // ---- B: pieces ---------------------------------------------------------------------
+        int total = 0;
+        (void)block_inclusive_scan(cnt, s_w, total);
+        const int chunk = max(8, (total + BWD_QUADS - 1) / BWD_QUADS);
+        // ceil(cnt / chunk) <= 32 (cnt <= 256, chunk >= 8) from the hardware reciprocal: exact,
+        // the quotient's fractional part is a multiple of 1/chunk
+        const float rchunk = __builtin_amdgcn_rcpf((float)chunk);
+        const int my_pieces = cnt ? (int)(((float)(cnt + chunk - 1) + 0.5f) * rchunk) : 0;
+        int n_pieces = 0;
+        const int incl = block_inclusive_scan(my_pieces, s_w, n_pieces);
+        if (tid < n) s_start[tid] = incl - my_pieces;
+        if (tid == 0) s_start[n] = n_pieces;
+        __syncthreads();
+        // ---- C: a quad per piece -----------------------------------------------------------
+        for (int p = quad; p < n_pieces; p += BWD_QUADS) {
+            int lo = 0, hi = n;  // last entry whose first piece is <= p
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_start[mid] <= p)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const int e = lo;
+            const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
+            const float gx = r0.x, gy = r0.y, a = r0.z, b = r0.w, c = r1.x, op = r1.y;
+            const float cr = r1.z, cg = r1.w, cb = r2.x;
+            const int rect = __float_as_int(r2.w);
+            const int x0 = rect & 255, x1 = (rect >> 8) & 255, y0 = (rect >> 16) & 255;
+            const int y1 = (rect >> 24) & 255;
+            const int w = x1 - x0 + 1, ecnt = w * (y1 - y0 + 1);
+            const int k_beg = (p - s_start[e]) * chunk, k_end = min(ecnt, k_beg + chunk);
+            // pixel k of the rectangle is (x0 + k % w, y0 + k / w); the quad's lanes take the
+            // piece's pixels round-robin.  Small quotients from the hardware reciprocal (exact:
+            // fractional parts are multiples of 1/w).
+            const float rw = __builtin_amdgcn_rcpf((float)w);
+            const int k0 = k_beg + q;
+            const int ky = (int)(((float)k0 + 0.5f) * rw);
+            int x = x0 + k0 - ky * w, y = y0 + ky;
+            const int step_y = (int)(4.0f * rw + 1.0e-3f), step_x = 4 - step_y * w;
+            const float pa = (-0.5f * LOG2E) * a, pb = (-LOG2E) * b, pc = (-0.5f * LOG2E) * c;
+            float acc[PART_STRIDE];
+#pragma unroll
+            for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
+            for (int k = k0; k < k_end; k += 4) {
+                const float dx = gx - (ox + (float)x), dy = gy - (oy + (float)y);
+                const float pp = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
+                const float ex = __builtin_amdgcn_exp2f(pp);
+                const float oe = op * ex;
+                const float alpha = fminf(cv.alpha_cap, oe);
+                const bool on = !(pp > 0.f || alpha < cv.alpha_min);
+                const float4 v = s_v[y * GI2D_BLOCK + x];
+                const float am = on ? alpha : 0.f;
+                acc[5] = __builtin_fmaf(am, v.x, acc[5]);
+                acc[6] = __builtin_fmaf(am, v.y, acc[6]);
+                acc[7] = __builtin_fmaf(am, v.z, acc[7]);
+                const float v_alpha = __builtin_fmaf(cb, v.z, __builtin_fmaf(cg, v.y, cr * v.x));
+                const bool live = on && !(oe > cv.alpha_cap);  // a capped alpha is a constant
+                const float va = live ? v_alpha : 0.f;
+                const float vs = -oe * va;
+                acc[8] = __builtin_fmaf(ex, va, acc[8]);
+                // moments of vs over the rectangle; the conic enters once, in step D
+                const float hx = vs * dx, hy = vs * dy;
+                acc[0] += hx;
+                acc[1] += hy;
+                acc[2] = __builtin_fmaf(hx, dx, acc[2]);
+                acc[3] = __builtin_fmaf(hx, dy, acc[3]);
+                acc[4] = __builtin_fmaf(hy, dy, acc[4]);
+                x += step_x;
+                y += step_y;
+                if (x > x1) {
+                    x -= w;
+                    ++y;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PART_STRIDE; ++k) acc[k] = quad_sum(acc[k]);
+            if (q == 0) {
+#pragma unroll
+                for (int k = 0; k < PART_STRIDE; ++k) s_piece[p * PART_STRIDE + k] = acc[k];
+            }
+        }
+        __syncthreads();
+        // ---- D: entry `tid` adds its pieces and stores -------------------------------------
+        if (tid < n) {
+            const float4 r0 = s_r0[tid], r1 = s_r1[tid], r2 = s_r2[tid];
+            const int gid = __float_as_int(r2.y), rad = __float_as_int(r2.z);
+            // index of this tile in the Gaussian's own (band-clipped) tile box: the first GSLOTS
+            // tiles write to the Gaussian's slots (with the stamp), the others to the tile's slab
+            TileBox box = tile_box(r0.x, r0.y, (float)rad, tiles_x, tiles_y);
+            const int by0 = max(box.y0, row0);
+            const int kb = (ty - by0) * (box.x1 - box.x0) + (tx - box.x0);
+            const bool own = rad > 0 && kb >= 0 && kb < GSLOTS;
+            // (an entry that cannot reach the tile leaves its own slot's old stamp: pass 2 then
+            // counts it as the zero it is; a slab slot is always written)
+            if (my_pieces > 0 || !own) {
+                float sum[PART_STRIDE];
+#pragma unroll
+                for (int k = 0; k < PART_STRIDE; ++k) sum[k] = 0.f;
+                const int p0 = s_start[tid];
+                for (int p = p0; p < p0 + my_pieces; ++p)
+#pragma unroll
+                    for (int k = 0; k < PART_STRIDE; ++k) sum[k] += s_piece[p * PART_STRIDE + k];
+                // v_xy = sum vs * (conic . d) = conic . (sum vs * d); v_conic = (1/2, 1, 1/2) * moments
+                const float a = r0.z, b = r0.w, c = r1.x;
+                const float m0 = sum[0], m1 = sum[1];
+                sum[0] = __builtin_fmaf(b, m1, a * m0);
+                sum[1] = __builtin_fmaf(c, m1, b * m0);
+                sum[2] *= 0.5f;
+                sum[4] *= 0.5f;
+                if (own) {
+                    float2 *dst = reinterpret_cast<float2 *>(
+                        gslots + ((size_t)kb * gslot_n + gid) * GSLOT_STRIDE);
+                    dst[0] = make_float2(sum[0], sum[1]);
+                    dst[1] = make_float2(sum[2], sum[3]);
+                    dst[2] = make_float2(sum[4], sum[5]);
+                    dst[3] = make_float2(sum[6], sum[7]);
+                    dst[4] = make_float2(sum[8], __int_as_float(stamp));
+                } else {
+                    float *dst = partials + (slot0 + base + tid) * PART_STRIDE;
+#pragma unroll
+                    for (int k = 0; k < PART_STRIDE; ++k) dst[k] = sum[k];
+                }
+            }
+        }
+        __syncthreads();  // the staging buffers are reused by the next batch
+    }
+}
+
+// (8 waves per SIMD: the two paths together would otherwise take 66 registers and lose a
+// workgroup per CU, which the latency-bound short-list tiles feel)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void
+rasterize_sum_bwd_kernel(
     const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
     const float *__restrict__ xys, const int *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
     int T, gi2d_conv cv, int cull, const float *__restrict__ v_out,
-    float *__restrict__ partials, float *__restrict__ gslots, int stamp)
+    float *__restrict__ partials, float *__restrict__ gslots, size_t gslot_n, int stamp)
 {
-    __shared__ float4 s_v[256];
-    __shared__ int s_first[64];
+    __shared__ float4 s_v[256];                       // the tile's v_out
+    __shared__ int s_first[64];                       // the list's first ids (short-list path)
+    __shared__ float4 s_r0[BWD_BATCH];                // gx, gy, a, b
+    __shared__ float4 s_r1[BWD_BATCH];                // c, opacity, red, green
+    __shared__ float4 s_r2[BWD_BATCH];                // blue, id, radius, rectangle (4 x 8 bits)
+    __shared__ int s_start[BWD_BATCH + 1];            // first piece of every entry
+    __shared__ int s_w[4];
+    __shared__ float s_piece[BWD_MAX_PIECES * PART_STRIDE];
     const int tid = threadIdx.x;
     const int t = xcd_tile(blockIdx.x, T);
     const int *lst = seg + (size_t)t * C;
-    // the first 64 ids before the length is known (a segment always has C >= 64 words)
-    if (tid < 64) s_first[tid] = lst[tid];
+    // the first ids before the length is known (a segment always has C >= 64 words)
+    const int gid_first = tid < min(C, BWD_BATCH) ? lst[tid] : 0;
     const int n_raw = tile_len[t];
     if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
     const size_t slot0 = (size_t)t * C;
@@ -169,22 +374,30 @@ __global__ __launch_bounds__(256) void rasterize_sum_bwd_kernel(
             v.z = p[2];
         }
         s_v[tid] = v;
+        if (tid < 64) s_first[tid] = gid_first;
     }
     __syncthreads();
-    // a short list gets more lanes per entry: its rectangles are walked in fewer steps
+    // Short lists: a fixed group of lanes per entry -- more lanes for fewer entries -- with next
+    // to no set-up.  Long lists (the fitted regime: many large Gaussians per tile) spend their
+    // time in the pixel loops, where the uneven supports of a wave's entries would leave most
+    // lanes idle: there the work is cut into equal pieces first.
 #define GI2D_BWD_TILE(LPE)                                                                      \
     bwd_tile<LPE>(lst, s_first, n_raw, slot0, tx, ty, s_v, xys, radii, conics, colors, opacity, \
-                  H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots, stamp)
+                  H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots, gslot_n, stamp)
     if (n_raw <= 16) GI2D_BWD_TILE(16);
-    else if (n_raw <= 32) GI2D_BWD_TILE(8);
-    else GI2D_BWD_TILE(4);
+    else if (n_raw <= BWD_PIECES_MIN_LIST) GI2D_BWD_TILE(8);
+    else
+        bwd_tile_pieces(lst, gid_first, n_raw, slot0, tx, ty, s_v, s_r0, s_r1, s_r2, s_start, s_w,
+                        s_piece, xys, radii, conics, colors, opacity, H, W, tiles_x, tiles_y, row0,
+                        cv, cull, partials, gslots, gslot_n, stamp);
 #undef GI2D_BWD_TILE
 }
 
 __global__ __launch_bounds__(256) void gather_grads_kernel(
     const float *__restrict__ xys, const int *__restrict__ radii, int N, int tiles_x, int tiles_y,
     int row0, int row1, const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
-    const float *__restrict__ partials, const float *__restrict__ gslots, int stamp,
+    const float *__restrict__ partials, const float *__restrict__ gslots, size_t gslot_n,
+    int stamp,
     float *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_colors,
     float *__restrict__ v_opacity)
 {
@@ -192,7 +405,7 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(
     if (g >= N) return;
     float acc[PART_STRIDE];
     gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
-                    tile_len, seg, C, partials, gslots, stamp, acc);
+                    tile_len, seg, C, partials, gslots, gslot_n, stamp, acc);
     v_xy[2 * g] = acc[0];
     v_xy[2 * g + 1] = acc[1];
     v_conic[3 * g] = acc[2];
@@ -241,7 +454,7 @@ int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
         rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(
             ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, colors, opacity, H, W,
             ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull, v_out,
-            ws->d_partials, ws->d_gslots, (int)ws->generation);
+            ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap, (int)ws->generation);
         rc = launch_status();
     }
     return rc;
@@ -268,8 +481,8 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
     if (rc != GI2D_OK) return rc;
     gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(
         xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, ws->d_len, ws->d_seg,
-        ws->seg_cap, ws->d_partials, ws->d_gslots, (int)ws->generation, v_xys, v_conics, v_colors,
-        v_opacity);
+        ws->seg_cap, ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap, (int)ws->generation, v_xys,
+        v_conics, v_colors, v_opacity);
     return launch_status();
 }
 

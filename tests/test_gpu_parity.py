@@ -687,7 +687,9 @@ def test_full_size_backward_properties(ops, oracle, H, W, N):
     img_o, _, gx_o, gc_o = run(c1, 1 - even)
     assert float((img_e + img_o - img1).abs().max()) <= 2e-5            # (c)
     m = even.bool().view(-1)
-    assert torch.equal(gc_e[m], gc1[m]) and torch.equal(gc_o[~m], gc1[~m])
+    # (equal up to the order of the partial sums, which follows the tile's total work)
+    assert _maxrel(_np(gc_e[m]), _np(gc1[m])) <= 2e-6
+    assert _maxrel(_np(gc_o[~m]), _np(gc1[~m])) <= 2e-6
     assert not gc_e[~m].any() and not gx_e[~m].any()
     assert _maxrel(_np(gx_e + gx_o), _np(gx1)) <= 1e-5
 
