@@ -815,3 +815,32 @@ def test_runtime_conventions_reach_every_kernel(ops, oracle, other_conventions, 
     args = (*dev, col.to(DEV), opa.to(DEV))
     pipe.forward(*args)
     assert torch.equal(pipe.forward(*args), img.detach())
+
+
+@pytest.mark.parametrize("H,W,N,fp", [(2160, 3840, 1000000, 1.0), (17, 5000, 20000, 2.0),
+                                      (4001, 23, 20000, 2.0), (1, 1, 50, 1.0)])
+def test_large_and_odd_shapes(ops, oracle, H, W, N, fp):
+    """A million Gaussians on a 4K frame, one-tile-high and one-tile-wide strips, a single
+    pixel: the one-call frame equals the operator path bit for bit, the backward's colour
+    gradient pairs with the forward (linearity), nothing is NaN."""
+    from gaussianimage_amd.pipeline import FramePipeline
+    means, L, col, op = (t.to(DEV) for t in synth.cholesky_inputs(N, seed=8, footprint=fp))
+    op = op.reshape(-1)
+    tb = oracle.tile_bounds(H, W)
+    proj = ops.project_gaussians_2d(means, L, H, W, tb)
+    ref = ops.rasterize_gaussians_sum(*proj, col, op.reshape(N, 1), H, W, 16, 16)
+    pipe = FramePipeline(N, H, W, device=DEV, workspace=ops.Workspace(DEV))
+    for _ in range(2):
+        img = pipe.forward(means, L, None, col, op)
+        assert torch.equal(img, ref)
+    assert torch.isfinite(img).all()
+    g = torch.Generator().manual_seed(1)
+    v = torch.randn(H, W, 3, generator=g).to(DEV)
+    grads = pipe.backward(means, L, None, col, op, v)
+    assert all(torch.isfinite(t).all() for t in grads if t is not None)
+    v_col = grads[3]
+    d = torch.rand(N, 3, generator=g).to(DEV)
+    img_d = pipe.forward(means, L, None, d, op)
+    lhs = float((img_d.double() * v.double()).sum())
+    rhs = float((v_col.double() * d.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0)
