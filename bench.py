@@ -272,7 +272,19 @@ def bench_concurrent(name, inputs, device, steps, streams=4):
     for k in range(steps):
         runs[k % streams]()
     torch.cuda.synchronize()
-    return {"fps_%d_streams" % streams: steps / (time.perf_counter() - t0)}
+    out = {"fps_%d_streams" % streams: steps / (time.perf_counter() - t0)}
+    # the same for ONE caller through the packaged ring (two frames in flight)
+    from gaussianimage_amd.pipeline import FrameRing
+    ring = FrameRing(N, H, W, kind=kind, device=device, depth=2)
+    for _ in range(10):
+        ring.render(*inputs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ring.render(*inputs, wait_inputs=False)
+    torch.cuda.synchronize()
+    out["fps_frame_ring_depth2"] = steps / (time.perf_counter() - t0)
+    return out
 
 
 def bench_fused_fit(name, device, steps, concurrent=True):

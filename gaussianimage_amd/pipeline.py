@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import BLOCK, check, lib
 from .ops import Workspace, _ptr, _stream, get_conventions
 
-__all__ = ["FramePipeline"]
+__all__ = ["FramePipeline", "FrameRing"]
 
 
 class FramePipeline:
@@ -203,3 +203,53 @@ class FramePipeline:
     def intersections(self):
         """Number of (tile, Gaussian) intersections of the last binning (synchronises)."""
         return int(self.ws.offsets()[-1].item())
+
+
+class FrameRing:
+    """``depth`` independent frames in flight for one caller: a ring of ``FramePipeline``s, each
+    with its own workspace, output buffers and HIP stream (default priority).  A single frame's
+    two kernels are latency-bound and leave most of the chip idle; consecutive frames of a
+    sequence (a video, a batch of images) do not depend on each other, so the projection of one
+    runs under the rasteriser of the one before.
+
+    ``render(...)`` issues the next frame and returns ``(image, event)``: the image buffer
+    belongs to the ring and is valid once ``event`` has completed (``event.synchronize()``, or
+    ``torch.cuda.current_stream().wait_event(event)`` before consuming it on another stream);
+    it is overwritten ``depth`` calls later.  Inputs are read on the ring's streams: they must
+    have been produced before the call on the caller's current stream (the ring waits for that
+    stream) and must not be overwritten until the returned event has completed.
+    """
+
+    def __init__(self, num_points, H, W, kind="cholesky", device="cuda:0", depth=2):
+        if depth < 1:
+            raise ValueError("depth >= 1 required")
+        self.device = torch.device(device)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        self.pipes, self.events = [], []
+        for st in self.streams:
+            with torch.cuda.stream(st):
+                self.pipes.append(FramePipeline(num_points, H, W, kind=kind, device=self.device))
+            self.events.append(torch.cuda.Event())
+        self.bound = [(None, None)] * depth
+        self.turn = 0
+
+    def render(self, means, cov_a, cov_b, colors, opacity, wait_inputs=True):
+        """``wait_inputs=False`` skips the wait for the caller's current stream (inputs that
+        were complete long ago, e.g. a resident model rendered repeatedly)."""
+        k = self.turn % len(self.pipes)
+        self.turn += 1
+        st = self.streams[k]
+        if wait_inputs:
+            st.wait_stream(torch.cuda.current_stream(self.device))  # inputs are ready there
+        tensors = (means, cov_a, cov_b, colors, opacity)
+        key = tuple(None if t is None else t.data_ptr() for t in tensors)
+        if self.bound[k][0] != key:   # the per-frame argument list is rebuilt only for new buffers
+            with torch.cuda.stream(st):
+                self.bound[k] = (key, self.pipes[k].bind(*tensors))
+        img = self.bound[k][1]()
+        self.events[k].record(st)
+        return img, self.events[k]
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()

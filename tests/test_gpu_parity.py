@@ -844,3 +844,24 @@ def test_large_and_odd_shapes(ops, oracle, H, W, N, fp):
     lhs = float((img_d.double() * v.double()).sum())
     rhs = float((v_col.double() * d.double()).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0)
+
+
+def test_frame_ring_renders_the_same_frames(ops, oracle):
+    """Frames issued through the two-deep ring equal the single-stream frames bit for bit,
+    whichever slot renders them, with inputs that change from frame to frame."""
+    from gaussianimage_amd.pipeline import FramePipeline, FrameRing
+    H, W, N = 96, 128, 2500
+    pipe = FramePipeline(N, H, W, device=DEV, workspace=ops.Workspace(DEV))
+    ring = FrameRing(N, H, W, device=DEV, depth=2)
+    frames = []
+    for seed in range(5):
+        means, L, col, op = (t.to(DEV) for t in synth.cholesky_inputs(N, seed=seed, footprint=1.5))
+        img, ev = ring.render(means, L, None, col, op.reshape(-1))
+        frames.append((img, ev, (means, L, col, op)))
+        if len(frames) >= 2:   # consume the frame before last while the last is in flight
+            old_img, old_ev, (m, l, c, o) = frames[-2]
+            old_ev.synchronize()
+            assert torch.equal(old_img, pipe.forward(m, l, None, c, o.reshape(-1)))
+    ring.synchronize()
+    img, ev, (m, l, c, o) = frames[-1]
+    assert torch.equal(img, pipe.forward(m, l, None, c, o.reshape(-1)))
