@@ -88,6 +88,8 @@ SIGNATURES = {
     "gi2d_fit_backward_step_chain": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp,
                                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           ctypes.POINTER(AdanHyper), _vp]),
+    "gi2d_fit_step": (_i, [_vp, _i] + [_vp] * 7 + [_i, _i, _i, _convp] + [_vp] * 11 +
+                      [ctypes.POINTER(AdanHyper), _vp]),
     "gi2d_decode_params": (_i, [_i, ctypes.POINTER(Codec), _i, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_decode_render": (_i, [_vp, _i, ctypes.POINTER(Codec), _vp, _vp, _i, _i, _i, _convp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -5,6 +5,8 @@
 #include "gather.h"
 #include "host.h"
 #include "projection.h"
+#include "raster_bwd_tile.h"
+#include "raster_fwd_tile.h"
 
 // ------------------------------------------------------------------------------------------
 // Adan step, fused: one launch over all parameter tensors, one read and one write of each of
@@ -125,6 +127,78 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward, loss and backward rasterisation of one tile in one workgroup.  For the L2 loss the
+// gradient with respect to a pixel depends on that pixel alone, so a tile that has rendered its
+// 256 pixels can go straight on to its backward pass: the loss gradient stays in LDS (it never
+// becomes an image in memory), the tile's sorted list is still at hand, and the backward of one
+// tile overlaps the forward of another instead of waiting for the whole frame behind a launch
+// boundary.  The arithmetic is that of rasterize_sum_fwd_kernel<.., L2> followed by
+// rasterize_sum_bwd_kernel: the same bits.
+// ------------------------------------------------------------------------------------------
+
+// LDS the two phases use one after the other: the forward's staging records, then the backward's
+// work-piece buffers
+#define FIT_POOL_BWD_INTS (3 * 4 * BWD_BATCH + (BWD_BATCH + 4) + BWD_MAX_PIECES * PART_STRIDE)
+#define FIT_POOL_FWD_INTS (FWD_LDS_INTS_PER_ENTRY * 256)
+#define FIT_POOL_INTS (FIT_POOL_BWD_INTS > FIT_POOL_FWD_INTS ? FIT_POOL_BWD_INTS : FIT_POOL_FWD_INTS)
+
+template <bool FINALIZE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void
+fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
+                  const int *__restrict__ radii, const float *__restrict__ conics,
+                  const float *__restrict__ colors, const float *__restrict__ opacity,
+                  const float *__restrict__ background, int H, int W, int tiles_x, int tiles_y,
+                  int row0, int T, gi2d_conv cv, int cull, DevStatus *status,
+                  long long generation, float *__restrict__ out, const float *__restrict__ gt,
+                  float *__restrict__ loss_part, float *__restrict__ partials,
+                  float *__restrict__ gslots, size_t gslot_n)
+{
+    __shared__ __attribute__((aligned(16))) int pool[FIT_POOL_INTS];
+    __shared__ float4 s_v[256];   // the tile's loss gradient
+    __shared__ int s_sorted[256]; // the tile's list, sorted (lists of up to 256 ids)
+    __shared__ int s_first[64];
+    __shared__ int s_w[4];
+    __shared__ float4 s_none[1];
+    const int n_raw = fwd_tile<FINALIZE, true, 1, 1, true>(
+        pool, s_none, s_v, s_sorted, tile_count, tile_len, seg, C, xys, conics, colors, opacity,
+        background, H, W, tiles_x, row0, T, cv, cull, status, generation, out, gt, nullptr,
+        loss_part, ExtraSets());
+    // (every wave is past its last read of the forward's records; the list, the loss gradient
+    // and the sorted ids are visible to the whole workgroup)
+    __syncthreads();
+    if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
+    const int tid = threadIdx.x;
+    const int t = xcd_tile(blockIdx.x, T);
+    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
+    const int *lst = seg + (size_t)t * C;
+    const size_t slot0 = (size_t)t * C;
+    int gid_first;
+    if (FINALIZE && n_raw <= 256)
+        gid_first = s_sorted[tid];
+    else
+        gid_first = tid < min(C, BWD_BATCH) ? lst[tid] : 0;
+    const int stamp = (int)generation;
+    if (n_raw <= BWD_PIECES_MIN_LIST) {
+        if (tid < 64) s_first[tid] = gid_first;
+        __syncthreads();
+#define GI2D_BWD_TILE(LPE)                                                                       \
+    bwd_tile<LPE>(lst, s_first, n_raw, slot0, tx, ty, s_v, xys, radii, conics, colors, opacity,  \
+                  H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots, gslot_n, stamp)
+        if (n_raw <= 16) GI2D_BWD_TILE(16);
+        else GI2D_BWD_TILE(8);
+#undef GI2D_BWD_TILE
+    } else {
+        float4 *s_r0 = reinterpret_cast<float4 *>(pool);
+        float4 *s_r1 = s_r0 + BWD_BATCH, *s_r2 = s_r1 + BWD_BATCH;
+        int *s_start = reinterpret_cast<int *>(s_r2 + BWD_BATCH);
+        float *s_piece = reinterpret_cast<float *>(s_start + BWD_BATCH + 4);
+        bwd_tile_pieces(lst, gid_first, n_raw, slot0, tx, ty, s_v, s_r0, s_r1, s_r2, s_start, s_w,
+                        s_piece, xys, radii, conics, colors, opacity, H, W, tiles_x, tiles_y, row0,
+                        cv, cull, partials, gslots, gslot_n, stamp);
+    }
+}
+
 __global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScalars h,
                                                         const float *__restrict__ clip_dev)
 {
@@ -177,6 +251,26 @@ static int adan_scalars(const gi2d_adan_hyper *hyper, AdanScalars &h)
 }
 
 
+// The projection of the raw parameters (skipped when a chained step has already done it into
+// these outputs) and the binning bookkeeping of a fitting iteration.
+static int fit_project_bin(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
+                           const float *cov_b, const float *opacity, int N, int H, int W,
+                           const gi2d_conv *conv, float *xys, float *depths, int *radii,
+                           float *conics, int *num_tiles_hit, void *stream)
+{
+    const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
+    const bool chained = ws->chain_pending && ws->prefilled && ws->chain_kind == kind &&
+                         ws->chain_xys == (const void *)xys && ws->pre_n == N &&
+                         ws->pre_tx == tiles_x && ws->pre_ty == tiles_y;
+    if (!chained) {
+        int rc = project_impl(kind, true, xyz, cov_a, cov_b, N, H, W, tiles_x, tiles_y, conv, xys,
+                              depths, radii, conics, num_tiles_hit, ws, stream, nullptr, nullptr,
+                              opacity);
+        if (rc != GI2D_OK) return rc;
+    }
+    return gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
+}
+
 extern "C" {
 
 int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
@@ -187,19 +281,8 @@ int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float
                      float *v_image, float *loss_partials, void *stream)
 {
     if (!ws || (kind != 0 && kind != 1) || !gt_chw) return GI2D_E_INVALID;
-    const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
-    int rc = GI2D_OK;
-    // a chained step has already projected these parameters into these outputs and filled the lists
-    const bool chained = ws->chain_pending && ws->prefilled && ws->chain_kind == kind &&
-                         ws->chain_xys == (const void *)xys && ws->pre_n == N &&
-                         ws->pre_tx == tiles_x && ws->pre_ty == tiles_y;
-    if (!chained) {
-        rc = project_impl(kind, true, xyz, cov_a, cov_b, N, H, W, tiles_x, tiles_y, conv, xys,
-                          depths, radii, conics, num_tiles_hit, ws, stream, nullptr, nullptr,
-                          opacity);
-        if (rc != GI2D_OK) return rc;
-    }
-    rc = gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
+    int rc = fit_project_bin(ws, kind, xyz, cov_a, cov_b, opacity, N, H, W, conv, xys, depths,
+                             radii, conics, num_tiles_hit, stream);
     if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
     const int late = rc;
     rc = raster_fwd_impl(ws, xys, conics, features, opacity, background, N, H, W, conv, image,
@@ -220,7 +303,7 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
                              const float *conics, const float *v_image, float *const *exp_avg,
                              float *const *exp_avg_sq, float *const *exp_avg_diff,
                              float *const *neg_pre_grad, const gi2d_adan_hyper *hyper,
-                             void *stream, const ChainOutputs *chain)
+                             void *stream, const ChainOutputs *chain, bool pass1_done = false)
 {
     if (kind != 0 && kind != 1) return GI2D_E_INVALID;
     int rc = check_raster_args(ws, N, H, W, conv);
@@ -231,7 +314,7 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
     if (N == 0) return GI2D_OK;
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (!xyz || !cov_a || (kind == 1 && !cov_b) || !features || !opacity || !xys || !radii ||
-        !conics || (!v_image && T > 0) || !exp_avg || !exp_avg_sq || !exp_avg_diff ||
+        !conics || (!v_image && T > 0 && !pass1_done) || !exp_avg || !exp_avg_sq || !exp_avg_diff ||
         !neg_pre_grad)
         return GI2D_E_INVALID;
     AdanTensors Tn;
@@ -251,8 +334,11 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
     }
     DeviceGuard guard(ws->device);
     hipStream_t st = (hipStream_t)stream;
-    rc = raster_bwd_pass1(ws, xys, radii, conics, features, opacity, N, H, W, conv, v_image, st);
-    if (rc != GI2D_OK) return rc;
+    if (!pass1_done) {
+        rc = raster_bwd_pass1(ws, xys, radii, conics, features, opacity, N, H, W, conv, v_image,
+                              st);
+        if (rc != GI2D_OK) return rc;
+    }
     const bool chained = chain != nullptr && begin_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y);
     ChainArgs ch = ChainArgs();
     if (chained) {
@@ -316,6 +402,57 @@ int gi2d_fit_backward_step_chain(gi2d_workspace *ws, int kind, float *xyz, float
     return fit_backward_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
                              radii, conics, v_image, exp_avg, exp_avg_sq, exp_avg_diff,
                              neg_pre_grad, hyper, stream, &chain);
+}
+
+int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                  float *features, const float *opacity, const float *background,
+                  const float *gt_chw, int N, int H, int W, const gi2d_conv *conv, float *xys,
+                  float *depths, int *radii, float *conics, int *num_tiles_hit, float *image,
+                  float *loss_partials, float *const *exp_avg, float *const *exp_avg_sq,
+                  float *const *exp_avg_diff, float *const *neg_pre_grad,
+                  const gi2d_adan_hyper *hyper, void *stream)
+{
+    if (!ws || (kind != 0 && kind != 1) || !gt_chw || !loss_partials || !hyper || hyper->step < 1)
+        return GI2D_E_INVALID;
+    if (!xys || !depths || !radii || !conics || !num_tiles_hit) return GI2D_E_INVALID;
+    if (N > 0 && (!xyz || !cov_a || (kind == 1 && !cov_b) || !features || !opacity))
+        return GI2D_E_INVALID;
+    if (conv && conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
+    int rc = fit_project_bin(ws, kind, xyz, cov_a, cov_b, opacity, N, H, W, conv, xys, depths,
+                             radii, conics, num_tiles_hit, stream);
+    if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
+    const int late = rc;
+    rc = check_raster_args(ws, N, H, W, conv);
+    if (rc != GI2D_OK) return rc;
+    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    if (T == 0) {  // empty band
+        ws->lists_raw = false;
+        return late;
+    }
+    DeviceGuard guard(ws->device);
+    hipStream_t st = (hipStream_t)stream;
+    rc = ensure_bwd_buffers(ws, N);
+    if (rc != GI2D_OK) return rc;
+#define GI2D_FIT_RASTER_ARGS ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, \
+                             features, opacity, background, H, W, ws->tiles_x, ws->tiles_y,      \
+                             ws->bin_row0, T, *conv, ws->cull, ws->d_status, ws->generation,     \
+                             image, gt_chw, loss_partials, ws->d_partials, ws->d_gslots,         \
+                             (size_t)ws->slot_cap
+    if (ws->lists_raw) {
+        fit_raster_kernel<true><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);
+        ws->lists_raw = false;
+        ws->counters_dirty = false;
+    } else {
+        fit_raster_kernel<false><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);
+    }
+#undef GI2D_FIT_RASTER_ARGS
+    rc = launch_status();
+    if (rc != GI2D_OK) return rc;
+    const ChainOutputs chain = {xys, depths, conics, radii, num_tiles_hit};
+    rc = fit_backward_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
+                           radii, conics, nullptr, exp_avg, exp_avg_sq, exp_avg_diff, neg_pre_grad,
+                           hyper, stream, &chain, true);
+    return rc != GI2D_OK ? rc : late;
 }
 
 int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,

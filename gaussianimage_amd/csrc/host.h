@@ -106,6 +106,7 @@ int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *conics, c
                     float *loss_part, void *stream, int sets = 1, ExtraSets extra = ExtraSets());
 
 // raster_bwd.hip
+int ensure_bwd_buffers(gi2d_workspace *ws, int N);
 int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii, const float *conics,
                      const float *colors, const float *opacity, int N, int H, int W,
                      const gi2d_conv *conv, const float *v_out, hipStream_t st);

@@ -1,8 +1,5 @@
 // raster_bwd.hip -- rasterize_gaussians_sum backward: per-tile partial sums, then their gather.
-#include "gather.h"
-#include "host.h"
-#include "support.h"
-#include "tiles.h"
+#include "raster_bwd_tile.h"
 
 // ------------------------------------------------------------------------------------------
 // rasterize_sum backward.
@@ -23,318 +20,6 @@
 // first GSLOTS tiles of its box lie in the Gaussian's own slots, the rest are found by binary
 // search (lists ascend in Gaussian id).
 // ------------------------------------------------------------------------------------------
-
-#define BWD_BATCH 128                  // entries per batch of the work-piece path
-// Lists longer than this take the work-piece path.  Measured on MI355X: a 50k-Gaussian fit of a
-// ~1020x768 image spends 37 us per backward in its fitted regime with the threshold at 64, 30 us
-// at 32 or 16; frames at initialisation (small supports) are unaffected either way.
-#define BWD_PIECES_MIN_LIST 32
-#define BWD_QUADS 64                   // quads of lanes per workgroup
-#define BWD_MAX_PIECES (BWD_BATCH + BWD_QUADS)
-
-// inclusive prefix sum over the 256 lanes of the workgroup (s_w: 4 ints of LDS); total in `all`
-__device__ __forceinline__ int block_inclusive_scan(int v, int *s_w, int &all)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
-    __syncthreads();  // (s_w may still be read from an earlier scan)
-    if (lane == 63) s_w[wave] = v;
-    __syncthreads();
-    const int w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-    all = w0 + w1 + w2 + w3;
-    return v + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
-}
-
-// sum over the LPE (4, 8 or 16) neighbouring lanes of an entry's group, result in every lane
-template <int LPE>
-__device__ __forceinline__ float group_sum(float v)
-{
-    v = quad_sum(v);
-    if (LPE >= 8) v = v + dpp_mov<0x141>(v);   // row_half_mirror: lane i <-> 7-i of each 8
-    if (LPE >= 16) v = v + dpp_mov<0x140>(v);  // row_mirror: lane i <-> 15-i of each 16
-    return v;
-}
-
-// The batches of one tile with LPE lanes per list entry (256 / LPE entries per batch).
-template <int LPE>
-__device__ __forceinline__ void bwd_tile(
-    const int *__restrict__ lst, const int *s_first, int n_raw, size_t slot0, int tx, int ty,
-    const float4 *s_v, const float *__restrict__ xys, const int *__restrict__ radii,
-    const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
-    const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
-    size_t gslot_n, int stamp)
-{
-    constexpr int EPB = 256 / LPE;  // entries per batch
-    const int tid = threadIdx.x;
-    const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
-    const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
-    const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
-    const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
-    const int q = tid & (LPE - 1);
-    for (int base = 0; base < n_raw; base += EPB) {
-        const int e = base + tid / LPE;
-        float acc[PART_STRIDE];
-#pragma unroll
-        for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
-        int gid = 0, rad = 0;
-        float gx = 0.f, gy = 0.f;
-        bool touched = false;  // the entry's support reaches this tile
-        if (e < n_raw) {
-            gid = base == 0 ? s_first[e] : lst[e];  // (the first 64 ids are already here)
-            gx = xys[2 * gid];
-            gy = xys[2 * gid + 1];
-            rad = radii[gid];
-            const float a = conics[3 * gid], b = conics[3 * gid + 1], c = conics[3 * gid + 2];
-            const float op = opacity[gid];
-            const float cr = colors[3 * gid], cg = colors[3 * gid + 1], cb = colors[3 * gid + 2];
-            int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
-            if (cull) support_rect(gx, gy, a, b, c, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
-            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-            const int cnt = (w > 0 && h > 0) ? w * h : 0;
-            touched = cnt > 0;
-            // The lanes of the group take the rectangle's pixels round-robin.  LPE / w and
-            // q / w for w in 1..16 from the hardware reciprocal (exact here: the quotients'
-            // fractional parts are multiples of 1/w, well clear of the 1-ulp error).
-            const float rw = __builtin_amdgcn_rcpf((float)max(w, 1));
-            const int step_y = cnt ? (int)((float)LPE * rw + 1.0e-3f) : 0;
-            const int step_x = cnt ? LPE - step_y * w : 0;
-            const int qy = (int)(((float)q + 0.5f) * rw);
-            int x = x0 + q - qy * w, y = y0 + qy;
-            const float pa = (-0.5f * LOG2E) * a, pb = (-LOG2E) * b, pc = (-0.5f * LOG2E) * c;
-            for (int k = q; k < cnt; k += LPE) {
-                const float dx = gx - (ox + (float)x), dy = gy - (oy + (float)y);
-                const float p = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
-                const float ex = __builtin_amdgcn_exp2f(p);
-                const float oe = op * ex;
-                const float alpha = fminf(cv.alpha_cap, oe);
-                const bool on = !(p > 0.f || alpha < cv.alpha_min);
-                const float4 v = s_v[y * GI2D_BLOCK + x];
-                const float am = on ? alpha : 0.f;
-                acc[5] = __builtin_fmaf(am, v.x, acc[5]);
-                acc[6] = __builtin_fmaf(am, v.y, acc[6]);
-                acc[7] = __builtin_fmaf(am, v.z, acc[7]);
-                const float v_alpha = __builtin_fmaf(cb, v.z, __builtin_fmaf(cg, v.y, cr * v.x));
-                const bool live = on && !(oe > cv.alpha_cap);  // a capped alpha is a constant
-                const float va = live ? v_alpha : 0.f;
-                const float vs = -oe * va;
-                acc[8] = __builtin_fmaf(ex, va, acc[8]);
-                // moments of vs over the rectangle; the conic enters once, after the loop
-                const float hx = vs * dx, hy = vs * dy;
-                acc[0] += hx;
-                acc[1] += hy;
-                acc[2] = __builtin_fmaf(hx, dx, acc[2]);
-                acc[3] = __builtin_fmaf(hx, dy, acc[3]);
-                acc[4] = __builtin_fmaf(hy, dy, acc[4]);
-                x += step_x;
-                y += step_y;
-                if (x > x1) {
-                    x -= w;
-                    ++y;
-                }
-            }
-            // v_xy = sum vs * (conic . d) = conic . (sum vs * d); v_conic = (1/2, 1, 1/2) * moments
-            const float m0 = acc[0], m1 = acc[1];
-            acc[0] = __builtin_fmaf(b, m1, a * m0);
-            acc[1] = __builtin_fmaf(c, m1, b * m0);
-            acc[2] *= 0.5f;
-            acc[4] *= 0.5f;
-        }
-#pragma unroll
-        for (int k = 0; k < PART_STRIDE; ++k) acc[k] = group_sum<LPE>(acc[k]);
-        if (e < n_raw && q == 0) {
-            // index of this tile in the Gaussian's own (band-clipped) tile box: the first GSLOTS
-            // tiles write to the Gaussian's slots (with the stamp), the others to the tile's slab
-            TileBox box = tile_box(gx, gy, (float)rad, tiles_x, tiles_y);
-            const int by0 = max(box.y0, row0);
-            const int kb = (ty - by0) * (box.x1 - box.x0) + (tx - box.x0);
-            if (rad > 0 && kb >= 0 && kb < GSLOTS) {
-                // (an entry that cannot reach the tile leaves its slot's old stamp: pass 2
-                // then counts it as the zero it is)
-                if (!touched) continue;
-                float2 *dst = reinterpret_cast<float2 *>(
-                    gslots + ((size_t)kb * gslot_n + gid) * GSLOT_STRIDE);
-                dst[0] = make_float2(acc[0], acc[1]);
-                dst[1] = make_float2(acc[2], acc[3]);
-                dst[2] = make_float2(acc[4], acc[5]);
-                dst[3] = make_float2(acc[6], acc[7]);
-                dst[4] = make_float2(acc[8], __int_as_float(stamp));
-            } else {
-                float *dst = partials + (slot0 + e) * PART_STRIDE;
-#pragma unroll
-                for (int k = 0; k < PART_STRIDE; ++k) dst[k] = acc[k];
-            }
-        }
-    }
-}
-
-// The work-piece path (long lists): the batches of one tile.
-__device__ __forceinline__ void bwd_tile_pieces(
-    const int *__restrict__ lst, int gid_first, int n_raw, size_t slot0, int tx, int ty,
-    const float4 *s_v, float4 *s_r0, float4 *s_r1, float4 *s_r2, int *s_start, int *s_w,
-    float *s_piece, const float *__restrict__ xys, const int *__restrict__ radii,
-    const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
-    const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
-    size_t gslot_n, int stamp)
-{
-    const int tid = threadIdx.x, q = tid & 3, quad = tid >> 2;
-    const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
-    const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
-    const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
-    const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
-    for (int base = 0; base < n_raw; base += BWD_BATCH) {
-        const int n = min(BWD_BATCH, n_raw - base);
-        // ---- A: stage entry `tid` ----------------------------------------------------------
-        int cnt = 0;
-        if (tid < n) {
-            const int gid = base == 0 ? gid_first : lst[base + tid];
-            const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
-            const float a = conics[3 * gid], b = conics[3 * gid + 1], c = conics[3 * gid + 2];
-            const float op = opacity[gid];
-            const int rad = radii[gid];
-            int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
-            if (cull) support_rect(gx, gy, a, b, c, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
-            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-            cnt = (w > 0 && h > 0) ? w * h : 0;
-            const int rect = cnt ? (x0 | (x1 << 8) | (y0 << 16) | (y1 << 24)) : 0;
-            s_r0[tid] = make_float4(gx, gy, a, b);
-            s_r1[tid] = make_float4(c, op, colors[3 * gid], colors[3 * gid + 1]);
-            s_r2[tid] = make_float4(colors[3 * gid + 2], __int_as_float(gid), __int_as_float(rad),
-                                    __int_as_float(rect));
-        }
-        // ---- B: pieces ---------------------------------------------------------------------
-        int total = 0;
-        (void)block_inclusive_scan(cnt, s_w, total);
-        const int chunk = max(8, (total + BWD_QUADS - 1) / BWD_QUADS);
-        // ceil(cnt / chunk) <= 32 (cnt <= 256, chunk >= 8) from the hardware reciprocal: exact,
-        // the quotient's fractional part is a multiple of 1/chunk
-        const float rchunk = __builtin_amdgcn_rcpf((float)chunk);
-        const int my_pieces = cnt ? (int)(((float)(cnt + chunk - 1) + 0.5f) * rchunk) : 0;
-        int n_pieces = 0;
-        const int incl = block_inclusive_scan(my_pieces, s_w, n_pieces);
-        if (tid < n) s_start[tid] = incl - my_pieces;
-        if (tid == 0) s_start[n] = n_pieces;
-        __syncthreads();
-        // ---- C: a quad per piece -----------------------------------------------------------
-        for (int p = quad; p < n_pieces; p += BWD_QUADS) {
-            int lo = 0, hi = n;  // last entry whose first piece is <= p
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_start[mid] <= p)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            const int e = lo;
-            const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
-            const float gx = r0.x, gy = r0.y, a = r0.z, b = r0.w, c = r1.x, op = r1.y;
-            const float cr = r1.z, cg = r1.w, cb = r2.x;
-            const int rect = __float_as_int(r2.w);
-            const int x0 = rect & 255, x1 = (rect >> 8) & 255, y0 = (rect >> 16) & 255;
-            const int y1 = (rect >> 24) & 255;
-            const int w = x1 - x0 + 1, ecnt = w * (y1 - y0 + 1);
-            const int k_beg = (p - s_start[e]) * chunk, k_end = min(ecnt, k_beg + chunk);
-            // pixel k of the rectangle is (x0 + k % w, y0 + k / w); the quad's lanes take the
-            // piece's pixels round-robin.  Small quotients from the hardware reciprocal (exact:
-            // fractional parts are multiples of 1/w).
-            const float rw = __builtin_amdgcn_rcpf((float)w);
-            const int k0 = k_beg + q;
-            const int ky = (int)(((float)k0 + 0.5f) * rw);
-            int x = x0 + k0 - ky * w, y = y0 + ky;
-            const int step_y = (int)(4.0f * rw + 1.0e-3f), step_x = 4 - step_y * w;
-            const float pa = (-0.5f * LOG2E) * a, pb = (-LOG2E) * b, pc = (-0.5f * LOG2E) * c;
-            float acc[PART_STRIDE];
-#pragma unroll
-            for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
-            for (int k = k0; k < k_end; k += 4) {
-                const float dx = gx - (ox + (float)x), dy = gy - (oy + (float)y);
-                const float pp = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
-                const float ex = __builtin_amdgcn_exp2f(pp);
-                const float oe = op * ex;
-                const float alpha = fminf(cv.alpha_cap, oe);
-                const bool on = !(pp > 0.f || alpha < cv.alpha_min);
-                const float4 v = s_v[y * GI2D_BLOCK + x];
-                const float am = on ? alpha : 0.f;
-                acc[5] = __builtin_fmaf(am, v.x, acc[5]);
-                acc[6] = __builtin_fmaf(am, v.y, acc[6]);
-                acc[7] = __builtin_fmaf(am, v.z, acc[7]);
-                const float v_alpha = __builtin_fmaf(cb, v.z, __builtin_fmaf(cg, v.y, cr * v.x));
-                const bool live = on && !(oe > cv.alpha_cap);  // a capped alpha is a constant
-                const float va = live ? v_alpha : 0.f;
-                const float vs = -oe * va;
-                acc[8] = __builtin_fmaf(ex, va, acc[8]);
-                // moments of vs over the rectangle; the conic enters once, in step D
-                const float hx = vs * dx, hy = vs * dy;
-                acc[0] += hx;
-                acc[1] += hy;
-                acc[2] = __builtin_fmaf(hx, dx, acc[2]);
-                acc[3] = __builtin_fmaf(hx, dy, acc[3]);
-                acc[4] = __builtin_fmaf(hy, dy, acc[4]);
-                x += step_x;
-                y += step_y;
-                if (x > x1) {
-                    x -= w;
-                    ++y;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PART_STRIDE; ++k) acc[k] = quad_sum(acc[k]);
-            if (q == 0) {
-#pragma unroll
-                for (int k = 0; k < PART_STRIDE; ++k) s_piece[p * PART_STRIDE + k] = acc[k];
-            }
-        }
-        __syncthreads();
-        // ---- D: entry `tid` adds its pieces and stores -------------------------------------
-        if (tid < n) {
-            const float4 r0 = s_r0[tid], r1 = s_r1[tid], r2 = s_r2[tid];
-            const int gid = __float_as_int(r2.y), rad = __float_as_int(r2.z);
-            // index of this tile in the Gaussian's own (band-clipped) tile box: the first GSLOTS
-            // tiles write to the Gaussian's slots (with the stamp), the others to the tile's slab
-            TileBox box = tile_box(r0.x, r0.y, (float)rad, tiles_x, tiles_y);
-            const int by0 = max(box.y0, row0);
-            const int kb = (ty - by0) * (box.x1 - box.x0) + (tx - box.x0);
-            const bool own = rad > 0 && kb >= 0 && kb < GSLOTS;
-            // (an entry that cannot reach the tile leaves its own slot's old stamp: pass 2 then
-            // counts it as the zero it is; a slab slot is always written)
-            if (my_pieces > 0 || !own) {
-                float sum[PART_STRIDE];
-#pragma unroll
-                for (int k = 0; k < PART_STRIDE; ++k) sum[k] = 0.f;
-                const int p0 = s_start[tid];
-                for (int p = p0; p < p0 + my_pieces; ++p)
-#pragma unroll
-                    for (int k = 0; k < PART_STRIDE; ++k) sum[k] += s_piece[p * PART_STRIDE + k];
-                // v_xy = sum vs * (conic . d) = conic . (sum vs * d); v_conic = (1/2, 1, 1/2) * moments
-                const float a = r0.z, b = r0.w, c = r1.x;
-                const float m0 = sum[0], m1 = sum[1];
-                sum[0] = __builtin_fmaf(b, m1, a * m0);
-                sum[1] = __builtin_fmaf(c, m1, b * m0);
-                sum[2] *= 0.5f;
-                sum[4] *= 0.5f;
-                if (own) {
-                    float2 *dst = reinterpret_cast<float2 *>(
-                        gslots + ((size_t)kb * gslot_n + gid) * GSLOT_STRIDE);
-                    dst[0] = make_float2(sum[0], sum[1]);
-                    dst[1] = make_float2(sum[2], sum[3]);
-                    dst[2] = make_float2(sum[4], sum[5]);
-                    dst[3] = make_float2(sum[6], sum[7]);
-                    dst[4] = make_float2(sum[8], __int_as_float(stamp));
-                } else {
-                    float *dst = partials + (slot0 + base + tid) * PART_STRIDE;
-#pragma unroll
-                    for (int k = 0; k < PART_STRIDE; ++k) dst[k] = sum[k];
-                }
-            }
-        }
-        __syncthreads();  // the staging buffers are reused by the next batch
-    }
-}
 
 // (8 waves per SIMD: the two paths together would otherwise take 66 registers and lose a
 // workgroup per CU, which the latency-bound short-list tiles feel)
@@ -421,15 +106,9 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(
 // host side
 // ------------------------------------------------------------------------------------------
 
-// Backward pass 1 (per-tile partial sums into the slab); shared by the operator backward and
-// the fused fitting step.
-int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
-                            const float *conics, const float *colors, const float *opacity, int N,
-                            int H, int W, const gi2d_conv *conv, const float *v_out,
-                            hipStream_t st)
+// The partial-sum buffers of the backward: the tiles' slab and the Gaussians' own slots.
+int ensure_bwd_buffers(gi2d_workspace *ws, int N)
 {
-    int rc = finalize_lists(ws, st);
-    if (rc != GI2D_OK) return rc;
     const int64_t slots = (int64_t)ws->tiles_cap * ws->seg_cap;
     if (ws->part_slots < slots) {
         HIP_TRY(hipDeviceSynchronize());
@@ -449,6 +128,20 @@ int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
         HIP_TRY(hipMemset(ws->d_gslots, 0, bytes));  // stamp 0 = never written (stamps are >= 1)
         ws->slot_cap = N;
     }
+    return GI2D_OK;
+}
+
+// Backward pass 1 (per-tile partial sums into the slab); shared by the operator backward and
+// the fused fitting step.
+int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
+                            const float *conics, const float *colors, const float *opacity, int N,
+                            int H, int W, const gi2d_conv *conv, const float *v_out,
+                            hipStream_t st)
+{
+    int rc = finalize_lists(ws, st);
+    if (rc != GI2D_OK) return rc;
+    rc = ensure_bwd_buffers(ws, N);
+    if (rc != GI2D_OK) return rc;
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (T > 0) {
         rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(

@@ -1,0 +1,282 @@
+// raster_fwd_tile.h -- the forward rasteriser's work for one tile (shared by the forward kernels
+// and the fused fitting kernel).
+#pragma once
+#include "host.h"
+#include "support.h"
+#include "tiles.h"
+
+// Tile counts from which the forward rasteriser switches to 2 / 4 pixels per lane.  Measured on
+// MI355X (kernel time, first pass): 3840x2160 / 200k (32 400 tiles, ~15 Gaussians per tile)
+// 59 / 44 / 38 us with 1 / 2 / 4; ~1020x768 / 50k (10 752 tiles) 14.6 / 14.6 / 20.3 us;
+// 768x512 / 30k (1536 tiles, ~48 per tile) 10 / 11.5 / 18 us.
+#define GI2D_PPL2_MIN_TILES 12288
+#define GI2D_PPL4_MIN_TILES 20480
+// LDS words per staged entry: two float4 records, blue, quadrant mask, id.  A workgroup of
+// BATCH lanes holds BATCH entries (11 KB for 256 lanes, 2.75 KB for 64: the small shapes need
+// the small footprint to reach their occupancy); the same words are the sort buffer of a list
+// longer than one batch.
+#define FWD_LDS_INTS_PER_ENTRY 11
+
+// L2 = true adds the fitting loop's epilogue (gaussianimage_cholesky.py:83-85,104 with
+// utils.py:24-25): clamp to [0,1], L2 loss against the target (stored [3,H,W] like the model's
+// gt_image), and the gradient of the mean-squared error with respect to the unclamped image
+// written to `v_img` [H,W,3]; each tile leaves its sum of squared errors in loss_part[tile].
+//
+// SETS > 1 renders further colour sets of the same Gaussians in the same pass (the model's
+// forward rasterises three colour tensors over one projection,
+// gaussianimage_cholesky.py:81-97): the geometry, the culling and the alpha of a (pixel,
+// Gaussian) pair are computed once and feed 3*SETS accumulators.
+
+//
+// PPL (pixels per lane) = 1, 2 or 4 shrinks the workgroup to 4, 2 or 1 waves, each wave
+// rendering PPL quadrants.  A frame of many sparse tiles is bound by the chain of dependent
+// memory rounds of each workgroup, not by arithmetic; smaller workgroups put 2x / 4x as many
+// tiles in flight per CU.  Every pixel still adds its Gaussians in list order, so all variants
+// give the same bits.
+//
+// KEEP = true (the fused fitting kernel; with L2, one pixel per lane): the loss gradient of the
+// tile's pixels stays in LDS (keep_v[ly * 16 + lx]) instead of going to v_img, and a list of up
+// to 256 ids that this pass sorts (FINALIZE) is also left, sorted, in keep_ids.
+// `smem` holds FWD_LDS_INTS_PER_ENTRY * (256 / PPL) ints (16-byte aligned), `s_x` the extra
+// colour sets' records.  Returns the tile's raw list length.
+template <bool FINALIZE, bool L2, int SETS, int PPL, bool KEEP>
+__device__ __forceinline__ int fwd_tile(
+    int *smem, float4 *s_x, float4 *keep_v, int *keep_ids, int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, const float *__restrict__ background, int H, int W,
+    int tiles_x,
+    int row0, int T, gi2d_conv cv, int cull, DevStatus *status, long long generation,
+    float *__restrict__ out, const float *__restrict__ gt, float *__restrict__ v_img,
+    float *__restrict__ loss_part, ExtraSets extra)
+{
+    static_assert(SETS >= 1 && SETS <= 3 && !(L2 && SETS > 1), "unsupported variant");
+    static_assert(PPL == 1 || ((PPL == 2 || PPL == 4) && SETS == 1), "unsupported variant");
+    static_assert(!KEEP || (L2 && PPL == 1), "unsupported variant");
+    constexpr int BATCH = 256 / PPL;            // lanes of the workgroup = entries staged at once
+    constexpr int NX = 3 * (SETS - 1);          // extra colour floats per entry
+    constexpr int NX4 = (NX + 3) / 4;           // ... in float4 records
+    constexpr int FWD_LDS_INTS = FWD_LDS_INTS_PER_ENTRY * BATCH;
+    // s_x: record q of entry k of the extra sets at [q*256+k]
+    float4 *s_a = reinterpret_cast<float4 *>(smem);         // gx, gy, -0.5*a*log2e, -b*log2e
+    float4 *s_b = reinterpret_cast<float4 *>(smem + 4 * BATCH);  // -0.5*c*log2e, opacity, r, g
+    float *s_c = reinterpret_cast<float *>(smem + 8 * BATCH);    // b
+    int *s_m = smem + 9 * BATCH;                            // quadrant mask (bit = 2*qy + qx)
+    int *s_id = smem + 10 * BATCH;                          // ids of the batch (rank sort)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = xcd_tile(blockIdx.x, T);
+    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
+    // this wave's quadrants are wave*PPL .. wave*PPL+PPL-1; a lane is the same pixel of each
+    float px[PPL], py[PPL], r[PPL], g[PPL], b[PPL];
+    size_t pix[PPL];
+    bool inside[PPL];
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+        const int q = wave * PPL + u;
+        const int lx = ((q & 1) << 3) + (lane & 7), ly = ((q >> 1) << 3) + (lane >> 3);
+        const int j = tx * GI2D_BLOCK + lx, i = ty * GI2D_BLOCK + ly;
+        inside[u] = (i < H) && (j < W);
+        px[u] = (float)j + cv.pixel_offset;
+        py[u] = (float)i + cv.pixel_offset;
+        pix[u] = (size_t)(i - row0 * GI2D_BLOCK) * W + j;
+        r[u] = g[u] = b[u] = 0.f;
+    }
+    int *lst = seg + (size_t)t * C;
+    // the first batch's id is loaded before the list length is known (a segment always has C
+    // words): one round trip to memory instead of two
+    int gid_first = tid < C ? lst[tid] : 0;
+    const int n_raw = FINALIZE ? tile_count[(size_t)t * CNT_STRIDE] : tile_len[t];
+    const int n_all = min(n_raw, C);
+    float xacc[NX ? NX : 1];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) xacc[q] = 0.f;
+    if (FINALIZE) {
+        __syncthreads();  // every wave has read the counter before lane 0 returns it to zero
+        if (n_all > BATCH) {  // long list: sort it where it lies before the batches are read
+            if (n_all <= FWD_LDS_INTS) {
+                for (int k = tid; k < n_all; k += BATCH) smem[k] = lst[k];
+                __syncthreads();
+                bitonic_sort(smem, n_all, tid, BATCH);
+                for (int k = tid; k < n_all; k += BATCH) lst[k] = smem[k];
+            } else {
+                bitonic_sort(lst, n_all, tid, BATCH);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) finalize_tile_words(t, n_raw, C, tile_count, tile_len, status, generation);
+    }
+    const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
+    const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
+    const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
+    const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
+    for (int base = 0; base < n_all; base += BATCH) {
+        const int n = min(BATCH, n_all - base);
+        __syncthreads();
+        // (a long list was just re-sorted in place: the early copy of its first ids is stale)
+        const bool early = base == 0 && !(FINALIZE && n_all > BATCH);
+        const int gid = tid < n ? (early ? gid_first : lst[base + tid]) : INT_MAX;
+        int slot = tid;
+        if (FINALIZE && n_all <= BATCH) {
+            // rank of my id among the batch = its place in ascending order (ids are distinct)
+            s_id[tid] = gid;
+            __syncthreads();
+            if (tid < n) {  // (waves wholly past the list skip the counting)
+                int rank = 0;
+                for (int k = 0; k < n; k += 4) {
+                    const int4 q = *reinterpret_cast<const int4 *>(s_id + k);
+                    rank += (q.x < gid ? 1 : 0) + (q.y < gid ? 1 : 0) + (q.z < gid ? 1 : 0) +
+                            (q.w < gid ? 1 : 0);
+                }
+                lst[rank] = gid;
+                if (KEEP) keep_ids[rank] = gid;
+                slot = rank;
+            }
+        }
+        int mask = 0;
+        if (tid < n) {
+            const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
+            const float ca = conics[3 * gid], cb = conics[3 * gid + 1], cc = conics[3 * gid + 2];
+            const float op = opacity[gid];
+            s_a[slot] = make_float4(gx, gy, (-0.5f * LOG2E) * ca, (-LOG2E) * cb);
+            s_b[slot] = make_float4((-0.5f * LOG2E) * cc, op, colors[3 * gid], colors[3 * gid + 1]);
+            s_c[slot] = colors[3 * gid + 2];
+            if (NX) {
+                float xc[NX4 ? 4 * NX4 : 1];
+#pragma unroll
+                for (int q = 0; q < 4 * NX4; ++q)
+                    xc[q] = q < NX ? extra.colors[q / 3][3 * gid + q % 3] : 0.f;
+#pragma unroll
+                for (int q = 0; q < NX4; ++q)
+                    s_x[q * 256 + slot] =
+                        make_float4(xc[4 * q], xc[4 * q + 1], xc[4 * q + 2], xc[4 * q + 3]);
+            }
+            int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
+            if (cull) support_rect(gx, gy, ca, cb, cc, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
+            if (x0 <= x1 && y0 <= y1) {
+                const int mx = (x0 < 8 ? 1 : 0) | (x1 >= 8 ? 2 : 0);
+                const int my = (y0 < 8 ? 1 : 0) | (y1 >= 8 ? 2 : 0);
+                mask = ((my & 1) ? mx : 0) | ((my & 2) ? (mx << 2) : 0);
+            }
+        }
+        s_m[slot] = mask;  // lanes past the batch keep slot = tid >= n and store 0
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int m = s_m[c0 + lane];
+#pragma unroll
+            for (int u = 0; u < PPL; ++u) {
+                unsigned long long bits = __ballot((m >> (wave * PPL + u)) & 1);
+                while (bits) {
+                    const int k = c0 + (int)__builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    const float4 A = s_a[k];
+                    const float4 B = s_b[k];
+                    const float cb = s_c[k];
+                    const float dx = A.x - px[u], dy = A.y - py[u];
+                    // p = -sigma*log2(e) = (A'dx + B'dy)dx + C'dy*dy
+                    const float q = __builtin_fmaf(A.w, dy, A.z * dx);
+                    const float p = __builtin_fmaf(B.x * dy, dy, q * dx);
+                    const float e = __builtin_amdgcn_exp2f(p);
+                    const float alpha = fminf(cv.alpha_cap, B.y * e);
+                    const float w = (p > 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
+                    r[u] = __builtin_fmaf(B.z, w, r[u]);
+                    g[u] = __builtin_fmaf(B.w, w, g[u]);
+                    b[u] = __builtin_fmaf(cb, w, b[u]);
+                    if (NX) {
+#pragma unroll
+                        for (int q4 = 0; q4 < NX4; ++q4) {
+                            const float4 X = s_x[q4 * 256 + k];
+                            const float xv[4] = {X.x, X.y, X.z, X.w};
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (4 * q4 + v < NX)
+                                    xacc[4 * q4 + v] =
+                                        __builtin_fmaf(xv[v], w, xacc[4 * q4 + v]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // the background is read on the device (three uniform loads) and only when it counts
+    float bg[3] = {0.f, 0.f, 0.f};
+    if (cv.bg_weight != 0.f) {
+        bg[0] = background[0];
+        bg[1] = background[1];
+        bg[2] = background[2];
+    }
+    float sq[PPL];
+    float keep_vo[3] = {0.f, 0.f, 0.f};  // (pixels outside the image keep a zero gradient)
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+        float rr = r[u] + cv.bg_weight * bg[0];
+        float gg = g[u] + cv.bg_weight * bg[1];
+        float bb = b[u] + cv.bg_weight * bg[2];
+        if (n_raw > C) rr = gg = bb = __builtin_nanf("");  // overflowed segment: never silently wrong
+        if (inside[u] && out != nullptr) {
+            float *o = out + 3 * pix[u];
+            o[0] = rr;
+            o[1] = gg;
+            o[2] = bb;
+        }
+        if (inside[u] && extra.out_chw != nullptr) {
+            float *o = extra.out_chw + pix[u];
+            // torch.clamp keeps a NaN (the overflow marker must survive); fmin/fmax would drop it
+            o[0] = rr != rr ? rr : fminf(fmaxf(rr, 0.f), 1.f);
+            o[extra.chw_plane] = gg != gg ? gg : fminf(fmaxf(gg, 0.f), 1.f);
+            o[2 * extra.chw_plane] = bb != bb ? bb : fminf(fmaxf(bb, 0.f), 1.f);
+        }
+        sq[u] = 0.f;
+        if (L2 && inside[u]) {
+            const size_t plane = (size_t)H * W;
+            const size_t gp = pix[u] + (size_t)(row0 * GI2D_BLOCK) * W;  // index in the full frame
+            const float scale = 2.0f / (3.0f * (float)plane);
+            const float v[3] = {rr, gg, bb};
+            float vo[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float x = v[ch];
+                const float d = fminf(fmaxf(x, 0.f), 1.f) - gt[ch * plane + gp];
+                sq[u] = __builtin_fmaf(d, d, sq[u]);
+                vo[ch] = (x >= 0.f && x <= 1.f) ? scale * d : 0.f;  // clamp passes its interior
+            }
+            if (!KEEP) {
+                float *dst = v_img + 3 * pix[u];
+                dst[0] = vo[0];
+                dst[1] = vo[1];
+                dst[2] = vo[2];
+            } else {
+                keep_vo[0] = vo[0];
+                keep_vo[1] = vo[1];
+                keep_vo[2] = vo[2];
+            }
+        }
+    }
+    if (NX && inside[0]) {
+        const float *bgs = bg;
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            float v = xacc[q] + cv.bg_weight * bgs[q % 3];
+            if (n_raw > C) v = __builtin_nanf("");
+            extra.out[q / 3][3 * pix[0] + q % 3] = v;
+        }
+    }
+    if (KEEP) {
+        const int lx = ((wave & 1) << 3) + (lane & 7), ly = ((wave >> 1) << 3) + (lane >> 3);
+        keep_v[ly * GI2D_BLOCK + lx] = make_float4(keep_vo[0], keep_vo[1], keep_vo[2], 0.f);
+    }
+    if (L2) {
+        // tile sum in a fixed order whatever the variant: the lanes of a quadrant by butterfly,
+        // the four quadrants through LDS
+        __syncthreads();
+        float *s_red = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) {
+            float v = sq[u];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+            if (lane == 0) s_red[wave * PPL + u] = v;
+        }
+        __syncthreads();
+        if (tid == 0) loss_part[t] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+    return n_raw;
+}

@@ -1,9 +1,11 @@
 """Fused fitting loop: the reference's ``train_iter`` (forward, L2 loss, backward, Adan step --
 /root/reference/gaussianimage_cholesky.py:101-124, /root/reference/gaussianimage_rs.py:82-95)
-in three launches on the model's raw parameters, with no gradient tensors and no host
-synchronisation (``gi2d_fit_forward`` + ``gi2d_fit_backward_step_chain``: rasterise with the loss
-epilogue; backward rasterisation; per Gaussian the gradient gather, the Adan update and, in the
-same lane, the projection of the updated parameters for the next iteration).
+in two launches on the model's raw parameters, with no gradient tensors and no host
+synchronisation (``gi2d_fit_step``: per tile the rasteriser with the loss epilogue followed at
+once by the tile's backward pass; per Gaussian the gradient gather, the Adan update and, in the
+same lane, the projection of the updated parameters for the next iteration).  The three- and
+four-launch forms (``gi2d_fit_forward`` + ``gi2d_fit_backward_step[_chain]``) stay available
+through ``one_pass=False`` / ``chain=False`` and give the same bits.
 
 This is an optional fast path beside the drop-in operators (which the reference's own model
 files keep using unchanged).  Parameter names and shapes are the reference model's
@@ -25,7 +27,8 @@ __all__ = ["FusedFitter"]
 class FusedFitter:
     def __init__(self, num_points, H, W, kind="cholesky", device="cuda:0", lr=1e-3,
                  betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0, no_prox=False,
-                 lr_step=20000, lr_gamma=0.5, params=None, keep_image=True, chain=True):
+                 lr_step=20000, lr_gamma=0.5, params=None, keep_image=True, chain=True,
+                 one_pass=True):
         if kind not in ("cholesky", "rs"):
             raise ValueError("kind must be 'cholesky' or 'rs'")
         self.kind, self.N, self.H, self.W = kind, int(num_points), int(H), int(W)
@@ -57,6 +60,9 @@ class FusedFitter:
         # iteration (one launch fewer).  The parameter tensors' versions tell whether anything
         # but the fused step touched them in between; if so the next forward projects afresh.
         self.chain = bool(chain)
+        # one_pass: forward and backward rasterisation in one kernel (gi2d_fit_step, two launches
+        # per iteration; implies the chained tail).  False keeps the separate calls.
+        self.one_pass = bool(one_pass) and self.chain
         self._versions = None
         self.overflowed_frames = 0  # iterations in which some tile list overflowed (see forward)
         self.ws = Workspace(d)
@@ -95,6 +101,12 @@ class FusedFitter:
                             ctypes.byref(self.conv), _ptr(self.xys), _ptr(self.depths),
                             _ptr(self.radii), _ptr(self.conics), _ptr(self.num_tiles_hit),
                             _ptr(self.v_image), *self._state_arrays)
+        self._step_head = (self.ws.handle, self._kind, _ptr(p[0]), _ptr(p[1]), _ptr(p[2]),
+                           _ptr(p[3]), _ptr(self._opacity), _ptr(self.background))
+        self._step_tail = (self.N, self.H, self.W, ctypes.byref(self.conv), _ptr(self.xys),
+                           _ptr(self.depths), _ptr(self.radii), _ptr(self.conics),
+                           _ptr(self.num_tiles_hit), _ptr(self.image), _ptr(self.loss_partials),
+                           *self._state_arrays)
         self._stream = _stream(self.device)
 
     @property
@@ -102,8 +114,7 @@ class FusedFitter:
         """StepLR(step_size, gamma) of the reference (gaussianimage_cholesky.py:55,123)."""
         return self.lr0 * self.lr_gamma ** (self.step_count // self.lr_step)
 
-    def forward(self, gt_image):
-        """Renders and evaluates the loss gradient; ``gt_image``: [1,3,H,W] or [3,H,W] float32."""
+    def _check_target(self, gt_image):
         if gt_image.device != self.device or gt_image.dtype != torch.float32 or \
                 not gt_image.is_contiguous() or gt_image.numel() != 3 * self.H * self.W:
             raise ValueError("gt_image must be a contiguous float32 [1,3,H,W] tensor on the device")
@@ -113,22 +124,39 @@ class FusedFitter:
                 check(lib.gi2d_workspace_set_option(self.ws.handle, _lib.OPT_DROP_PENDING, 1),
                       "gi2d_workspace_set_option")
             self._versions = None
-        rc = lib.gi2d_fit_forward(*self._fwd_args, _ptr(gt_image), *self._fwd_tail, self._stream)
+
+    def _late_overflow(self, rc):
         if rc == _lib.GI2D_E_PREV_OVERFLOW:
             # An EARLIER iteration outgrew a tile list (Gaussians grow while fitting): its
             # overflowed tiles contributed no loss gradient for that one step, the lists have
             # been enlarged since, and this iteration is complete.  Nothing to repair in a fit.
             self.overflowed_frames += 1
             rc = 0
-        check(rc, "gi2d_fit_forward")
+        return rc
+
+    def forward(self, gt_image):
+        """Renders and evaluates the loss gradient; ``gt_image``: [1,3,H,W] or [3,H,W] float32."""
+        self._check_target(gt_image)
+        rc = lib.gi2d_fit_forward(*self._fwd_args, _ptr(gt_image), *self._fwd_tail, self._stream)
+        check(self._late_overflow(rc), "gi2d_fit_forward")
 
     def step(self, gt_image):
         """One fitting iteration (forward, loss, backward, Adan).  Returns nothing: read
         ``loss()`` / ``psnr()`` when needed -- they synchronise, the step does not."""
         lr = self.lr
+        b1, b2, b3 = self.betas
+        if self.one_pass:
+            self._check_target(gt_image)
+            self.step_count += 1
+            hyper = _lib.AdanHyper(lr, b1, b2, b3, self.eps, self.weight_decay,
+                                   int(bool(self.no_prox)), self.step_count)
+            rc = lib.gi2d_fit_step(*self._step_head, _ptr(gt_image), *self._step_tail,
+                                   ctypes.byref(hyper), self._stream)
+            self._versions = self._param_versions()
+            check(self._late_overflow(rc), "gi2d_fit_step")
+            return
         self.forward(gt_image)
         self.step_count += 1
-        b1, b2, b3 = self.betas
         hyper = _lib.AdanHyper(lr, b1, b2, b3, self.eps, self.weight_decay,
                                int(bool(self.no_prox)), self.step_count)
         if self.chain:

@@ -246,6 +246,24 @@ int gi2d_fit_backward_step_chain(gi2d_workspace *ws, int kind, float *xyz, float
                                  float *const *neg_pre_grad, const gi2d_adan_hyper *hyper,
                                  void *stream);
 
+/* One whole fitting iteration in one call and TWO launches: gi2d_fit_forward
+ * and gi2d_fit_backward_step_chain with the two rasterisation passes in one
+ * kernel.  With the L2 loss the gradient at a pixel depends on that pixel
+ * alone, so a tile that has rendered goes straight on to its backward pass:
+ * the loss gradient stays on chip (there is no v_image), the tile's sorted
+ * list is used twice.  Same arithmetic, same results as the two calls.
+ * image[H,W,3] optional (NULL to skip); loss_partials[tiles] as above.  Returns
+ * as gi2d_fit_forward does (GI2D_E_PREV_OVERFLOW = this iteration is complete,
+ * an earlier one lost some tiles).  No counterpart in the reference (its loop
+ * is Python: gaussianimage_cholesky.py:101-124). */
+int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                  float *features, const float *opacity, const float *background,
+                  const float *gt_chw, int N, int H, int W, const gi2d_conv *conv, float *xys,
+                  float *depths, int *radii, float *conics, int *num_tiles_hit, float *image,
+                  float *loss_partials, float *const *exp_avg, float *const *exp_avg_sq,
+                  float *const *exp_avg_diff, float *const *neg_pre_grad,
+                  const gi2d_adan_hyper *hyper, void *stream);
+
 /* ---- codec decode path ------------------------------------------------------
  * The coded attributes of one image, as compress_wo_ec() leaves them
  * (gaussianimage_cholesky.py:154-159, gaussianimage_rs.py:125-130) together

@@ -112,36 +112,65 @@ def test_growing_gaussians_do_not_stop_a_fit():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["cholesky", "rs"])
-def test_chained_step_is_the_plain_step(kind):
-    """The step whose tail also projects the next iteration (3 launches) leaves, bit for bit, the
+@pytest.mark.parametrize("kind,N", [("cholesky", 2500), ("rs", 2500), ("cholesky", 150),
+                                    ("cholesky", 12000)])
+def test_chained_and_one_pass_steps_are_the_plain_step(kind, N):
+    """The step whose tail also projects the next iteration (3 launches), and the one that also
+    runs both rasterisation passes in one kernel (2 launches), leave, bit for bit, the
     parameters, optimizer state and losses of the plain 4-launch step -- also across an outside
-    modification of the parameters between two iterations, which must not be missed."""
+    modification of the parameters between two iterations, which must not be missed.  The three
+    sizes give short lists (groups of lanes per entry), lists of some tens (work pieces) and
+    lists beyond one staging batch."""
     from gaussianimage_amd.fit import FusedFitter
-    H, W, N = 96, 112, 2500
+    H, W = 96, 112
     gt = synth.target_image(H, W).to(DEV)
     fits = []
-    for chain in (True, False):
+    for chain, one_pass in ((True, True), (True, False), (False, False)):
         torch.manual_seed(7)
-        fits.append(FusedFitter(N, H, W, kind=kind, device=DEV, chain=chain))
-    losses = [[], []]
+        fits.append(FusedFitter(N, H, W, kind=kind, device=DEV, chain=chain, one_pass=one_pass))
+    assert fits[0].one_pass and not fits[1].one_pass
+    losses = [[], [], []]
     for it in range(9):
         for k, f in enumerate(fits):
             if it == 5:  # someone edits the parameters behind the fitter's back
                 f.params["_xyz"].mul_(0.9)
             f.step(gt)
             losses[k].append(f.loss())
-    assert losses[0] == losses[1]
-    a, b = fits
+    assert losses[0] == losses[2] and losses[1] == losses[2]
+    b = fits[2]
+    for a in fits[:2]:
+        for k in a.params:
+            assert torch.equal(a.params[k], b.params[k]), k
+            for s in a.state[k]:
+                assert torch.equal(a.state[k][s], b.state[k][s]), (k, s)
+    # the chained fitters' projection outputs are those of the parameters as they are now
+    for f in fits:
+        f.forward(gt)
+    for a in fits[:2]:
+        assert torch.equal(a.xys, b.xys) and torch.equal(a.radii, b.radii)
+        assert torch.equal(a.conics, b.conics) and torch.equal(a.v_image, b.v_image)
+        assert torch.equal(a.image, b.image)
+
+
+@pytest.mark.gpu
+def test_one_pass_step_keeps_the_image_and_survives_forward_calls_in_between():
+    """gi2d_fit_step writes the optional image like the forward does, and explicit forward()
+    calls between steps (which consume the lists the chained tail prepared) change nothing."""
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N = 70, 90, 1800   # edge tiles in both directions
+    gt = synth.target_image(H, W).to(DEV)
+    torch.manual_seed(3)
+    a = FusedFitter(N, H, W, device=DEV)
+    torch.manual_seed(3)
+    b = FusedFitter(N, H, W, device=DEV, chain=False)
+    for it in range(6):
+        a.step(gt)
+        b.step(gt)
+        assert torch.equal(a.image, b.image), it
+        if it % 2:
+            a.forward(gt)
     for k in a.params:
         assert torch.equal(a.params[k], b.params[k]), k
-        for s in a.state[k]:
-            assert torch.equal(a.state[k][s], b.state[k][s]), (k, s)
-    # the chained fitter's projection outputs are those of the parameters as they are now
-    b.forward(gt)
-    a.forward(gt)
-    assert torch.equal(a.xys, b.xys) and torch.equal(a.radii, b.radii)
-    assert torch.equal(a.conics, b.conics) and torch.equal(a.v_image, b.v_image)
 
 
 @pytest.mark.gpu
