@@ -84,17 +84,30 @@ def time_cpu_oracle(name, budget_s=12.0):
         offs, ids = cport.bin_tiles(xys, radii, H, W)
         return cport.rasterize_sum_fwd(xys, conics, col, op, H, W, offs, ids)
 
-    frame()
-    n, t0 = 0, time.perf_counter()
-    while True:
+    def run(budget, most):
         frame()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 200:
-            break
-    return {"value": n / el, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} forward frames of {name} (project+bin+rasterize) in {el:.1f} s; "
-                      "rasterize loop OpenMP-parallel over tiles, projection and binning serial"}
+        n, t0 = 0, time.perf_counter()
+        while True:
+            frame()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget or n >= most:
+                return n, el
+
+    n, el = run(budget_s, 200)
+    out = {"value": n / el, "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"{n} forward frames of {name} (project+bin+rasterize) in {el:.1f} s; "
+                     "rasterize loop OpenMP-parallel over tiles, projection and binning serial"}
+    try:  # the same on one core (a few frames), as a second reference point
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        n1, el1 = run(4.0, 20)
+        gomp.omp_set_num_threads(threads)
+        out["single_core_value"] = n1 / el1
+    except OSError:
+        pass
+    return out
 
 
 def bench_forward(pipe, inputs, steps, warmup, sync_all):
@@ -420,6 +433,8 @@ def main():
                      "traffic": traffic, "algorithmic_bytes_per_launch": bytes_raster,
                      "avg_launch_ms": raster_avg_ms,
                      "median_launch_ms": raster_ms[len(raster_ms) // 2],
+                     "p10_launch_ms": raster_ms[len(raster_ms) // 10],
+                     "p90_launch_ms": raster_ms[(9 * len(raster_ms)) // 10],
                      "empty_event_bracket_ms": empty_bracket_ms},
     }
 
