@@ -185,6 +185,31 @@ def _tile_bounds_check(name, H, W, tile_bounds):
     return tx, ty
 
 
+class _NoGradCtx:
+    """Stands in for the autograd context when nothing is to be recorded."""
+    hw = opacity_shape = None
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+_NO_GRAD_CTX = _NoGradCtx()
+
+
+def _call(fn, differentiable, *args):
+    """``fn.apply(*args)``; under ``torch.no_grad()`` (the reference's FPS and test loops,
+    train.py:242,258) or when no differentiable input requires a gradient, the forward runs
+    directly: the autograd bookkeeping of ``apply`` is a third of such a call's host time."""
+    if torch.is_grad_enabled():
+        for t in differentiable:
+            if t.requires_grad:
+                return fn.apply(*args)
+    return fn.forward(_NO_GRAD_CTX, *args)
+
+
 def _alloc_proj(N, device):
     return (torch.empty(N, 2, dtype=torch.float32, device=device),
             torch.empty(N, dtype=torch.float32, device=device),
@@ -387,8 +412,8 @@ def project_gaussians_2d(means2d, L_elements, img_height, img_width, tile_bounds
         raise ValueError("means2d must have shape (N, 2)")
     if L_elements.ndimension() != 2 or L_elements.shape != (means2d.shape[0], 3):
         raise ValueError("L_elements must have shape (N, 3)")
-    return _ProjectGaussians2d.apply(means2d, L_elements, int(img_height), int(img_width),
-                                     tuple(tile_bounds))
+    return _call(_ProjectGaussians2d, (means2d, L_elements), means2d, L_elements,
+                 int(img_height), int(img_width), tuple(tile_bounds))
 
 
 def project_gaussians_2d_scale_rot(means2d, scales2d, rotation, img_height, img_width,
@@ -402,8 +427,8 @@ def project_gaussians_2d_scale_rot(means2d, scales2d, rotation, img_height, img_
         raise ValueError("scales2d must have shape (N, 2)")
     if rotation.numel() != N:
         raise ValueError("rotation must have shape (N, 1)")
-    return _ProjectGaussians2dScaleRot.apply(means2d, scales2d, rotation, int(img_height),
-                                             int(img_width), tuple(tile_bounds))
+    return _call(_ProjectGaussians2dScaleRot, (means2d, scales2d, rotation), means2d, scales2d,
+                 rotation, int(img_height), int(img_width), tuple(tile_bounds))
 
 
 def rasterize_gaussians_sum(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
@@ -431,8 +456,9 @@ def rasterize_gaussians_sum(xys, depths, radii, conics, num_tiles_hit, colors, o
                     ("opacity", opacity)):
         if t.shape[0] != N:
             raise ValueError(f"{name} has {t.shape[0]} rows, xys has {N}")
-    out = _RasterizeGaussiansSum.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
-                                       int(img_height), int(img_width), background)
+    out = _call(_RasterizeGaussiansSum, (xys, conics, colors, opacity), xys, depths, radii,
+                conics, num_tiles_hit, colors, opacity, int(img_height), int(img_width),
+                background)
     if return_alpha:
         # never requested by the reference's 2D models; alpha of a sum has no transmittance
         # meaning, so the accumulated weight of a white colour set is returned
@@ -470,5 +496,6 @@ def rasterize_gaussians_sum_multi(xys, depths, radii, conics, num_tiles_hit, col
     for name, t in (("radii", radii), ("conics", conics), ("opacity", opacity)):
         if t.shape[0] != N:
             raise ValueError(f"{name} has {t.shape[0]} rows, xys has {N}")
-    return _RasterizeGaussiansSumMulti.apply(xys, depths, radii, conics, num_tiles_hit, opacity,
-                                             int(img_height), int(img_width), background, *colors)
+    return _call(_RasterizeGaussiansSumMulti, (xys, conics, opacity, *colors), xys, depths,
+                 radii, conics, num_tiles_hit, opacity, int(img_height), int(img_width),
+                 background, *colors)

@@ -865,3 +865,28 @@ def test_frame_ring_renders_the_same_frames(ops, oracle):
     ring.synchronize()
     img, ev, (m, l, c, o) = frames[-1]
     assert torch.equal(img, pipe.forward(m, l, None, c, o.reshape(-1)))
+
+
+def test_no_grad_calls_give_the_same_tensors(ops):
+    """Under torch.no_grad() (and for inputs that need no gradient) the operators skip the
+    autograd bookkeeping; what they return is unchanged."""
+    H, W, N = 64, 80, 900
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    means, L, col, op = (t.to(DEV) for t in synth.cholesky_inputs(N, seed=3, footprint=1.5))
+    mg, Lg, cg = (t.clone().requires_grad_(True) for t in (means, L, col))
+    with_grad = ops.project_gaussians_2d(mg, Lg, H, W, tb)
+    img_grad = ops.rasterize_gaussians_sum(*with_grad, cg, op, H, W, 16, 16)
+    assert img_grad.requires_grad and with_grad[0].requires_grad
+    for ctxmgr in (torch.no_grad(), torch.enable_grad()):
+        with ctxmgr:
+            a = ops.project_gaussians_2d(mg if ctxmgr.__class__ is torch.no_grad else means,
+                                         Lg if ctxmgr.__class__ is torch.no_grad else L, H, W, tb)
+            img = ops.rasterize_gaussians_sum(*a, col, op, H, W, 16, 16)
+            three = ops.rasterize_gaussians_sum_multi(*a, [col, col * 0.5, torch.ones_like(col)],
+                                                      op, H, W)
+        assert not img.requires_grad and not a[0].requires_grad
+        for x, y in zip(a, with_grad):
+            assert torch.equal(x, y.detach())
+        assert torch.equal(img, img_grad.detach()) and torch.equal(three[0], img)
+    img_grad.sum().backward()   # the recorded path is intact
+    assert torch.isfinite(mg.grad).all() and torch.isfinite(cg.grad).all()
