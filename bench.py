@@ -418,6 +418,21 @@ def main():
             traffic = json.load(open(tpath)).get(args.workload, {}).get("rasterize_sum_fwd_kernel")
         except Exception:
             traffic = None
+    # wave-level VALU instructions of the rasteriser launch (SQ_INSTS_VALU from a counters-only
+    # rocprofv3 pass of this workload, kept under profiles/) against the chip's issue rate:
+    # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+    valu = None
+    mpath = os.path.join(ROOT, "profiles", "r01_sq_instruction_mix.json")
+    if os.path.exists(mpath):
+        try:
+            mix = json.load(open(mpath)).get(args.workload, {})
+            for name, c in mix.items():
+                if "rasterize_sum_fwd_kernel<true, false, 1" in name:
+                    peak = 256 * 4 * 2.4e9 / 4
+                    valu = {"instr_per_launch": c["SQ_INSTS_VALU"], "peak_instr_per_s": peak,
+                            "frac": c["SQ_INSTS_VALU"] / peak / (raster_avg_ms * 1e-3)}
+        except Exception:
+            valu = None
     result = {
         "metric": "render FPS (forward: project + tile binning + rasterize_sum), 768x512 @ 30k "
                   "Gaussians" if args.workload == "kodak30k" else f"render FPS, {args.workload}",
@@ -435,7 +450,7 @@ def main():
                      "median_launch_ms": raster_ms[len(raster_ms) // 2],
                      "p10_launch_ms": raster_ms[len(raster_ms) // 10],
                      "p90_launch_ms": raster_ms[(9 * len(raster_ms)) // 10],
-                     "empty_event_bracket_ms": empty_bracket_ms},
+                     "empty_event_bracket_ms": empty_bracket_ms, "valu_issue": valu},
     }
 
     if not args.no_extras and rank == 0:

@@ -19,11 +19,16 @@ ap.add_argument("--points", type=int, default=50000)
 ap.add_argument("--height", type=int, default=768)
 ap.add_argument("--width", type=int, default=1020)
 ap.add_argument("--kind", default="cholesky")
+ap.add_argument("--footprint", type=float, default=1.0,
+                help="scale of the initial Cholesky factors (3 = supports like a fitted model's)")
 args = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(1)
 fit = FusedFitter(args.points, args.height, args.width, kind=args.kind, device=dev, lr=1e-3,
                   keep_image=False)
+if args.footprint != 1.0 and args.kind == "cholesky":
+    bound = torch.tensor([0.5, 0.0, 0.5], device=dev)
+    fit.params["_cholesky"].copy_((fit.params["_cholesky"] + bound) * args.footprint - bound)
 gt = synth.target_image(args.height, args.width).to(dev)
 marks = {}
 torch.cuda.synchronize()
