@@ -302,12 +302,21 @@ def bench_concurrent(name, inputs, device, steps, streams=4):
 
 def bench_fused_fit(name, device, steps, concurrent=True):
     """The fused fitting iteration (gaussianimage_amd/fit.py): forward, L2 loss, backward and
-    Adan step in four launches on the raw parameters, no host synchronisation inside the loop."""
+    Adan step in two launches on the raw parameters, no host synchronisation inside the loop.
+    The workload's footprint scales the initial Cholesky factors as it does the forward inputs."""
     from gaussianimage_amd import synth
     from gaussianimage_amd.fit import FusedFitter
-    H, W, N, kind, _ = WORKLOADS[name]
+    H, W, N, kind, fp = WORKLOADS[name]
+
+    def make():
+        f = FusedFitter(N, H, W, kind=kind, device=device, keep_image=False)
+        if fp != 1.0 and kind == "cholesky":
+            bound = torch.tensor([0.5, 0.0, 0.5], device=device)
+            f.params["_cholesky"].copy_((f.params["_cholesky"] + bound) * fp - bound)
+        return f
+
     torch.manual_seed(1)
-    fit = FusedFitter(N, H, W, kind=kind, device=device, keep_image=False)
+    fit = make()
     gt = synth.target_image(H, W).to(device)
     for _ in range(10):
         fit.step(gt)
@@ -328,7 +337,7 @@ def bench_fused_fit(name, device, steps, concurrent=True):
     for _ in range(streams):
         st = torch.cuda.Stream(device=device)
         with torch.cuda.stream(st):
-            fits.append(FusedFitter(N, H, W, kind=kind, device=device, keep_image=False))
+            fits.append(make())
     torch.cuda.synchronize()
     for _ in range(5):
         for f in fits:
