@@ -139,47 +139,22 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
 
 // LDS the two phases use one after the other: the forward's staging records, then the backward's
 // work-piece buffers
-#define FIT_POOL_BWD_INTS (3 * 4 * BWD_BATCH + (BWD_BATCH + 4) + BWD_MAX_PIECES * PART_STRIDE)
-#define FIT_POOL_FWD_INTS (FWD_LDS_INTS_PER_ENTRY * 256)
-#define FIT_POOL_INTS (FIT_POOL_BWD_INTS > FIT_POOL_FWD_INTS ? FIT_POOL_BWD_INTS : FIT_POOL_FWD_INTS)
+#define FIT_POOL_BWD_INTS \
+    (3 * 4 * BWD_BATCH + (BWD_BATCH + 4) + BWD_MAX_PIECES * PART_STRIDE + BWD_MAX_PIECES / 4)
 
-template <bool FINALIZE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void
-fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
-                  const int *__restrict__ radii, const float *__restrict__ conics,
-                  const float *__restrict__ colors, const float *__restrict__ opacity,
-                  const float *__restrict__ background, int H, int W, int tiles_x, int tiles_y,
-                  int row0, int T, gi2d_conv cv, int cull, DevStatus *status,
-                  long long generation, float *__restrict__ out, const float *__restrict__ gt,
-                  float *__restrict__ loss_part, float *__restrict__ partials,
-                  float *__restrict__ gslots, size_t gslot_n)
+// The backward of one tile inside the fused kernel, workgroup of 256 lanes: direct paths for
+// short lists, equal work pieces beyond.
+__device__ __forceinline__ void fit_bwd_256(
+    int *pool, const float4 *s_v, int *s_w, const int *lst, int gid_first, int n_raw,
+    size_t slot0, int tx, int ty, const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
+    const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
+    size_t gslot_n, int stamp)
 {
-    __shared__ __attribute__((aligned(16))) int pool[FIT_POOL_INTS];
-    __shared__ float4 s_v[256];   // the tile's loss gradient
-    __shared__ int s_sorted[256]; // the tile's list, sorted (lists of up to 256 ids)
-    __shared__ int s_first[64];
-    __shared__ int s_w[4];
-    __shared__ float4 s_none[1];
-    const int n_raw = fwd_tile<FINALIZE, true, 1, 1, true>(
-        pool, s_none, s_v, s_sorted, tile_count, tile_len, seg, C, xys, conics, colors, opacity,
-        background, H, W, tiles_x, row0, T, cv, cull, status, generation, out, gt, nullptr,
-        loss_part, ExtraSets());
-    // (every wave is past its last read of the forward's records; the list, the loss gradient
-    // and the sorted ids are visible to the whole workgroup)
-    __syncthreads();
-    if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
     const int tid = threadIdx.x;
-    const int t = xcd_tile(blockIdx.x, T);
-    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
-    const int *lst = seg + (size_t)t * C;
-    const size_t slot0 = (size_t)t * C;
-    int gid_first;
-    if (FINALIZE && n_raw <= 256)
-        gid_first = s_sorted[tid];
-    else
-        gid_first = tid < min(C, BWD_BATCH) ? lst[tid] : 0;
-    const int stamp = (int)generation;
     if (n_raw <= BWD_PIECES_MIN_LIST) {
+        int *s_first = pool;  // (the forward's records are dead by now)
         if (tid < 64) s_first[tid] = gid_first;
         __syncthreads();
 #define GI2D_BWD_TILE(LPE)                                                                       \
@@ -193,10 +168,93 @@ fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *
         float4 *s_r1 = s_r0 + BWD_BATCH, *s_r2 = s_r1 + BWD_BATCH;
         int *s_start = reinterpret_cast<int *>(s_r2 + BWD_BATCH);
         float *s_piece = reinterpret_cast<float *>(s_start + BWD_BATCH + 4);
+        unsigned char *s_owner =
+            reinterpret_cast<unsigned char *>(s_piece + BWD_MAX_PIECES * PART_STRIDE);
         bwd_tile_pieces(lst, gid_first, n_raw, slot0, tx, ty, s_v, s_r0, s_r1, s_r2, s_start, s_w,
-                        s_piece, xys, radii, conics, colors, opacity, H, W, tiles_x, tiles_y, row0,
+                        s_piece, s_owner, xys, radii, conics, colors, opacity, H, W, tiles_x, tiles_y, row0,
                         cv, cull, partials, gslots, gslot_n, stamp);
     }
+}
+
+// ... and of a single wave (sparse frames: many tiles with a handful of Gaussians each): the
+// fewer entries, the more lanes each gets.
+__device__ __forceinline__ void fit_bwd_64(
+    int *pool, const float4 *s_v, const int *lst, int gid_first, int n_raw, size_t slot0, int tx,
+    int ty, const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
+    const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
+    size_t gslot_n, int stamp)
+{
+    int *s_first = pool;
+    s_first[threadIdx.x] = gid_first;
+    __syncthreads();
+#define GI2D_BWD_TILE(LPE)                                                                       \
+    bwd_tile<LPE, 64>(lst, s_first, n_raw, slot0, tx, ty, s_v, xys, radii, conics, colors,       \
+                      opacity, H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots, gslot_n, \
+                      stamp)
+    if (n_raw <= 4) GI2D_BWD_TILE(16);
+    else if (n_raw <= 8) GI2D_BWD_TILE(8);
+    else GI2D_BWD_TILE(4);
+#undef GI2D_BWD_TILE
+}
+
+// PPL = 1: 256 lanes per tile; PPL = 4: one wave per tile (the forward renders four pixels per
+// lane, the backward gives each entry 4 to 16 lanes and has no work-piece path).
+template <bool FINALIZE, int PPL>
+// (8 waves per SIMD for the 256-lane form, as in rasterize_sum_bwd_kernel; the one-wave form is
+// limited by its LDS)
+__global__ __launch_bounds__(256 / PPL)
+__attribute__((amdgpu_waves_per_eu(PPL == 1 ? 8 : 5, 8))) void
+fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
+                  const int *__restrict__ radii, const float *__restrict__ conics,
+                  const float *__restrict__ colors, const float *__restrict__ opacity,
+                  const float *__restrict__ background, int H, int W, int tiles_x, int tiles_y,
+                  int row0, int T, gi2d_conv cv, int cull, DevStatus *status,
+                  long long generation, float *__restrict__ out, const float *__restrict__ gt,
+                  float *__restrict__ loss_part, float *__restrict__ partials,
+                  float *__restrict__ gslots, size_t gslot_n)
+{
+    static_assert(PPL == 1 || PPL == 4, "unsupported variant");
+    constexpr int NT = 256 / PPL;
+    constexpr int FWD_INTS = FWD_LDS_INTS_PER_ENTRY * NT;
+    // LDS the two phases use one after the other (forward staging records, then the backward's
+    // buffers), with the tile's sorted list (lists of up to NT ids) behind the forward's
+    // records, in a part the backward writes only after every lane has fetched its id
+    constexpr int POOL_INTS =
+        PPL == 1 ? (FIT_POOL_BWD_INTS > FWD_INTS + NT ? FIT_POOL_BWD_INTS : FWD_INTS + NT)
+                 : FWD_INTS + NT;
+    __shared__ __attribute__((aligned(16))) int pool[POOL_INTS];
+    __shared__ float4 s_v[256];   // the tile's loss gradient
+    __shared__ int s_w[4];
+    int *s_sorted = pool + FWD_INTS;
+    const int n_raw = fwd_tile<FINALIZE, true, 1, PPL, true>(
+        pool, nullptr, s_v, s_sorted, tile_count, tile_len, seg, C, xys, conics, colors, opacity,
+        background, H, W, tiles_x, row0, T, cv, cull, status, generation, out, gt, nullptr,
+        loss_part, ExtraSets());
+    // (every wave is past its last read of the forward's records; the list, the loss gradient
+    // and the sorted ids are visible to the whole workgroup)
+    __syncthreads();
+    if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
+    const int tid = threadIdx.x;
+    const int t = xcd_tile(blockIdx.x, T);
+    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
+    const int *lst = seg + (size_t)t * C;
+    const size_t slot0 = (size_t)t * C;
+    int gid_first;
+    if (FINALIZE && n_raw <= NT)
+        gid_first = s_sorted[tid];
+    else
+        gid_first = tid < min(C, min(NT, BWD_BATCH)) ? lst[tid] : 0;
+    const int stamp = (int)generation;
+    if (PPL == 1)
+        fit_bwd_256(pool, s_v, s_w, lst, gid_first, n_raw, slot0, tx, ty, xys, radii, conics,
+                    colors, opacity, H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots,
+                    gslot_n, stamp);
+    else
+        fit_bwd_64(pool, s_v, lst, gid_first, n_raw, slot0, tx, ty, xys, radii, conics, colors,
+                   opacity, H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots, gslot_n,
+                   stamp);
 }
 
 __global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScalars h,
@@ -438,12 +496,15 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
                              ws->bin_row0, T, *conv, ws->cull, ws->d_status, ws->generation,     \
                              image, gt_chw, loss_partials, ws->d_partials, ws->d_gslots,         \
                              (size_t)ws->slot_cap
+    const bool one_wave = sparse_frame(ws, T);
     if (ws->lists_raw) {
-        fit_raster_kernel<true><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);
+        if (one_wave) fit_raster_kernel<true, 4><<<T, 64, 0, st>>>(GI2D_FIT_RASTER_ARGS);
+        else fit_raster_kernel<true, 1><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);
         ws->lists_raw = false;
         ws->counters_dirty = false;
     } else {
-        fit_raster_kernel<false><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);
+        if (one_wave) fit_raster_kernel<false, 4><<<T, 64, 0, st>>>(GI2D_FIT_RASTER_ARGS);
+        else fit_raster_kernel<false, 1><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);
     }
 #undef GI2D_FIT_RASTER_ARGS
     rc = launch_status();

@@ -81,6 +81,23 @@ struct ExtraSets {
     size_t chw_plane;        // rows * W of the band being rendered
 };
 
+// Tile counts from which the forward rasteriser switches to 2 / 4 pixels per lane.  Measured on
+// MI355X (kernel time, first pass): 3840x2160 / 200k (32 400 tiles, ~15 Gaussians per tile)
+// 59 / 44 / 38 us with 1 / 2 / 4; ~1020x768 / 50k (10 752 tiles) 14.6 / 14.6 / 20.3 us;
+// 768x512 / 30k (1536 tiles, ~48 per tile) 10 / 11.5 / 18 us.
+#define GI2D_PPL2_MIN_TILES 12288
+#define GI2D_PPL4_MIN_TILES 20480
+
+// A sparse frame -- many tiles, none of whose lists has ever held more than a wave's worth of
+// ids -- gets one wave per tile in the backward and in the fused fitting kernel (measured at
+// 3840x2160 / 200k: the 256-lane forms are bound by the VALU instructions their four waves spend
+// on a handful of entries).  The raster_ppl option forces the choice (4 = one wave).
+static inline bool sparse_frame(const gi2d_workspace *ws, int T)
+{
+    if (ws->raster_ppl != 0) return ws->raster_ppl == 4;
+    return T >= GI2D_PPL4_MIN_TILES && ws->h_status[0] <= 64;
+}
+
 // lists.hip
 int ensure_lists(gi2d_workspace *ws, int T, int C);
 int wanted_cap(const gi2d_workspace *ws, long long seen);

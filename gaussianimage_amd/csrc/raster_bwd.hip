@@ -33,13 +33,17 @@ rasterize_sum_bwd_kernel(
     float *__restrict__ partials, float *__restrict__ gslots, size_t gslot_n, int stamp)
 {
     __shared__ float4 s_v[256];                       // the tile's v_out
-    __shared__ int s_first[64];                       // the list's first ids (short-list path)
     __shared__ float4 s_r0[BWD_BATCH];                // gx, gy, a, b
     __shared__ float4 s_r1[BWD_BATCH];                // c, opacity, red, green
     __shared__ float4 s_r2[BWD_BATCH];                // blue, id, radius, rectangle (4 x 8 bits)
     __shared__ int s_start[BWD_BATCH + 1];            // first piece of every entry
     __shared__ int s_w[4];
     __shared__ float s_piece[BWD_MAX_PIECES * PART_STRIDE];
+    // entry (of the batch) a piece belongs to; the short-list path keeps the list's first 64
+    // ids in the same words
+    __shared__ __attribute__((aligned(16))) unsigned char s_owner[BWD_MAX_PIECES];
+    static_assert(BWD_MAX_PIECES >= 64 * sizeof(int), "s_first does not fit");
+    int *s_first = reinterpret_cast<int *>(s_owner);
     const int tid = threadIdx.x;
     const int t = xcd_tile(blockIdx.x, T);
     const int *lst = seg + (size_t)t * C;
@@ -73,8 +77,54 @@ rasterize_sum_bwd_kernel(
     else if (n_raw <= BWD_PIECES_MIN_LIST) GI2D_BWD_TILE(8);
     else
         bwd_tile_pieces(lst, gid_first, n_raw, slot0, tx, ty, s_v, s_r0, s_r1, s_r2, s_start, s_w,
-                        s_piece, xys, radii, conics, colors, opacity, H, W, tiles_x, tiles_y, row0,
+                        s_piece, s_owner, xys, radii, conics, colors, opacity, H, W, tiles_x, tiles_y, row0,
                         cv, cull, partials, gslots, gslot_n, stamp);
+#undef GI2D_BWD_TILE
+}
+
+// The same for sparse frames (many tiles with a handful of Gaussians each): ONE wave per tile,
+// each entry gets 4 to 16 lanes, no work-piece path.  Per tile it spends about half the
+// instructions of the 256-lane form, whose four waves all pay the per-entry set-up.
+__global__ __launch_bounds__(64) void rasterize_sum_bwd_wave_kernel(
+    const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
+    const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0, int row1,
+    int T, gi2d_conv cv, int cull, const float *__restrict__ v_out,
+    float *__restrict__ partials, float *__restrict__ gslots, size_t gslot_n, int stamp)
+{
+    __shared__ float4 s_v[256];
+    __shared__ int s_first[64];
+    const int tid = threadIdx.x;
+    const int t = xcd_tile(blockIdx.x, T);
+    const int *lst = seg + (size_t)t * C;
+    const int gid_first = tid < C ? lst[tid] : 0;  // before the length is known
+    const int n_raw = tile_len[t];
+    if (n_raw == 0 || n_raw > C) return;  // an overflowed tile is reported, not half-summed
+    const size_t slot0 = (size_t)t * C;
+    const int tx = t % tiles_x, ty = row0 + t / tiles_x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int px = u * 64 + tid;
+        const int j = tx * GI2D_BLOCK + (px & 15), i = ty * GI2D_BLOCK + (px >> 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < H && j < W) {
+            const float *p = v_out + 3 * ((size_t)(i - row0 * GI2D_BLOCK) * W + j);
+            v.x = p[0];
+            v.y = p[1];
+            v.z = p[2];
+        }
+        s_v[px] = v;
+    }
+    s_first[tid] = gid_first;
+    __syncthreads();
+#define GI2D_BWD_TILE(LPE)                                                                       \
+    bwd_tile<LPE, 64>(lst, s_first, n_raw, slot0, tx, ty, s_v, xys, radii, conics, colors,       \
+                      opacity, H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots, gslot_n, \
+                      stamp)
+    if (n_raw <= 4) GI2D_BWD_TILE(16);
+    else if (n_raw <= 8) GI2D_BWD_TILE(8);
+    else GI2D_BWD_TILE(4);
 #undef GI2D_BWD_TILE
 }
 
@@ -144,10 +194,15 @@ int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
     if (rc != GI2D_OK) return rc;
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (T > 0) {
-        rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(
-            ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, colors, opacity, H, W,
-            ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull, v_out,
-            ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap, (int)ws->generation);
+#define GI2D_BWD_ARGS ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, colors, opacity, H, W, \
+                      ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull,     \
+                      v_out, ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap,                   \
+                      (int)ws->generation
+        if (sparse_frame(ws, T))
+            rasterize_sum_bwd_wave_kernel<<<T, 64, 0, st>>>(GI2D_BWD_ARGS);
+        else
+            rasterize_sum_bwd_kernel<<<T, 256, 0, st>>>(GI2D_BWD_ARGS);
+#undef GI2D_BWD_ARGS
         rc = launch_status();
     }
     return rc;

@@ -10,9 +10,12 @@
 // Lists longer than this take the work-piece path.  Measured on MI355X: a 50k-Gaussian fit of a
 // ~1020x768 image spends 37 us per backward in its fitted regime with the threshold at 64, 30 us
 // at 32 or 16; frames at initialisation (small supports) are unaffected either way.
+#ifndef BWD_PIECES_MIN_LIST
 #define BWD_PIECES_MIN_LIST 32
+#endif
 #define BWD_QUADS 64                   // quads of lanes per workgroup
-#define BWD_MAX_PIECES (BWD_BATCH + BWD_QUADS)
+#define BWD_MAX_ROUNDS 4               // rounds of BWD_QUADS pieces a batch is cut into, at most
+#define BWD_MAX_PIECES (BWD_QUADS * BWD_MAX_ROUNDS)
 
 // inclusive prefix sum over the 256 lanes of the workgroup (s_w: 4 ints of LDS); total in `all`
 __device__ __forceinline__ int block_inclusive_scan(int v, int *s_w, int &all)
@@ -41,8 +44,9 @@ __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
-// The batches of one tile with LPE lanes per list entry (256 / LPE entries per batch).
-template <int LPE>
+// The batches of one tile with LPE lanes per list entry, in a workgroup of NT lanes (NT / LPE
+// entries per batch).
+template <int LPE, int NT = 256>
 __device__ __forceinline__ void bwd_tile(
     const int *lst, const int *s_first, int n_raw, size_t slot0, int tx, int ty,
     const float4 *s_v, const float *__restrict__ xys, const int *__restrict__ radii,
@@ -51,7 +55,7 @@ __device__ __forceinline__ void bwd_tile(
     const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
     size_t gslot_n, int stamp)
 {
-    constexpr int EPB = 256 / LPE;  // entries per batch
+    constexpr int EPB = NT / LPE;  // entries per batch
     const int tid = threadIdx.x;
     const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
     const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
@@ -158,7 +162,7 @@ __device__ __forceinline__ void bwd_tile(
 __device__ __forceinline__ void bwd_tile_pieces(
     const int *lst, int gid_first, int n_raw, size_t slot0, int tx, int ty,
     const float4 *s_v, float4 *s_r0, float4 *s_r1, float4 *s_r2, int *s_start, int *s_w,
-    float *s_piece, const float *__restrict__ xys, const int *__restrict__ radii,
+    float *s_piece, unsigned char *s_owner, const float *__restrict__ xys, const int *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
     const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
@@ -190,29 +194,42 @@ __device__ __forceinline__ void bwd_tile_pieces(
                                     __int_as_float(rect));
         }
         // ---- B: pieces ---------------------------------------------------------------------
+        // The batch's pixels are cut into about BWD_QUADS pieces per 32 entries (at most
+        // BWD_MAX_ROUNDS x BWD_QUADS): the quads then make that many rounds over pieces of about
+        // equal size.  With fewer, larger pieces a round lasts as long as its largest entry while
+        // most quads hold small ones (measured on fitted-size supports: 3 rounds of ~55 pixel
+        // steps for 128 entries, where 4 rounds of ~17 do).
         int total = 0;
         (void)block_inclusive_scan(cnt, s_w, total);
-        const int chunk = max(8, (total + BWD_QUADS - 1) / BWD_QUADS);
+        const int rounds = min(BWD_MAX_ROUNDS, (n + 31) >> 5);
+        // expected pieces = total / chunk + n / 2 (half a piece of rounding per entry)
+        int chunk = max(8, (int)((float)total * __builtin_amdgcn_rcpf(
+                                     (float)(BWD_QUADS * rounds - (n >> 1)))) + 1);
         // ceil(cnt / chunk) <= 32 (cnt <= 256, chunk >= 8) from the hardware reciprocal: exact,
         // the quotient's fractional part is a multiple of 1/chunk
-        const float rchunk = __builtin_amdgcn_rcpf((float)chunk);
-        const int my_pieces = cnt ? (int)(((float)(cnt + chunk - 1) + 0.5f) * rchunk) : 0;
+        float rchunk = __builtin_amdgcn_rcpf((float)chunk);
+        int my_pieces = cnt ? (int)(((float)(cnt + chunk - 1) + 0.5f) * rchunk) : 0;
         int n_pieces = 0;
-        const int incl = block_inclusive_scan(my_pieces, s_w, n_pieces);
-        if (tid < n) s_start[tid] = incl - my_pieces;
+        int incl = block_inclusive_scan(my_pieces, s_w, n_pieces);
+        if (n_pieces > BWD_MAX_PIECES) {
+            // (rare: many entries just over a multiple of the chunk)  sum ceil(cnt / chunk) <=
+            // total / chunk + n, so this chunk fits whatever the counts are
+            chunk = max(chunk, (int)((float)total * __builtin_amdgcn_rcpf(
+                                         (float)(BWD_MAX_PIECES - n))) + 2);
+            rchunk = __builtin_amdgcn_rcpf((float)chunk);
+            my_pieces = cnt ? (int)(((float)(cnt + chunk - 1) + 0.5f) * rchunk) : 0;
+            incl = block_inclusive_scan(my_pieces, s_w, n_pieces);
+        }
+        if (tid < n) {
+            const int p0 = incl - my_pieces;
+            s_start[tid] = p0;
+            for (int j = 0; j < my_pieces; ++j) s_owner[p0 + j] = (unsigned char)tid;
+        }
         if (tid == 0) s_start[n] = n_pieces;
         __syncthreads();
         // ---- C: a quad per piece -----------------------------------------------------------
         for (int p = quad; p < n_pieces; p += BWD_QUADS) {
-            int lo = 0, hi = n;  // last entry whose first piece is <= p
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_start[mid] <= p)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            const int e = lo;
+            const int e = s_owner[p];
             const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
             const float gx = r0.x, gy = r0.y, a = r0.z, b = r0.w, c = r1.x, op = r1.y;
             const float cr = r1.z, cg = r1.w, cb = r2.x;

@@ -5,12 +5,6 @@
 #include "support.h"
 #include "tiles.h"
 
-// Tile counts from which the forward rasteriser switches to 2 / 4 pixels per lane.  Measured on
-// MI355X (kernel time, first pass): 3840x2160 / 200k (32 400 tiles, ~15 Gaussians per tile)
-// 59 / 44 / 38 us with 1 / 2 / 4; ~1020x768 / 50k (10 752 tiles) 14.6 / 14.6 / 20.3 us;
-// 768x512 / 30k (1536 tiles, ~48 per tile) 10 / 11.5 / 18 us.
-#define GI2D_PPL2_MIN_TILES 12288
-#define GI2D_PPL4_MIN_TILES 20480
 // LDS words per staged entry: two float4 records, blue, quadrant mask, id.  A workgroup of
 // BATCH lanes holds BATCH entries (11 KB for 256 lanes, 2.75 KB for 64: the small shapes need
 // the small footprint to reach their occupancy); the same words are the sort buffer of a list
@@ -34,9 +28,9 @@
 // tiles in flight per CU.  Every pixel still adds its Gaussians in list order, so all variants
 // give the same bits.
 //
-// KEEP = true (the fused fitting kernel; with L2, one pixel per lane): the loss gradient of the
-// tile's pixels stays in LDS (keep_v[ly * 16 + lx]) instead of going to v_img, and a list of up
-// to 256 ids that this pass sorts (FINALIZE) is also left, sorted, in keep_ids.
+// KEEP = true (the fused fitting kernel; with L2): the loss gradient of the tile's pixels stays
+// in LDS (keep_v[ly * 16 + lx]) instead of going to v_img, and a list of up to one batch
+// (256 / PPL) of ids that this pass sorts (FINALIZE) is also left, sorted, in keep_ids.
 // `smem` holds FWD_LDS_INTS_PER_ENTRY * (256 / PPL) ints (16-byte aligned), `s_x` the extra
 // colour sets' records.  Returns the tile's raw list length.
 template <bool FINALIZE, bool L2, int SETS, int PPL, bool KEEP>
@@ -51,7 +45,7 @@ __device__ __forceinline__ int fwd_tile(
 {
     static_assert(SETS >= 1 && SETS <= 3 && !(L2 && SETS > 1), "unsupported variant");
     static_assert(PPL == 1 || ((PPL == 2 || PPL == 4) && SETS == 1), "unsupported variant");
-    static_assert(!KEEP || (L2 && PPL == 1), "unsupported variant");
+    static_assert(!KEEP || L2, "unsupported variant");
     constexpr int BATCH = 256 / PPL;            // lanes of the workgroup = entries staged at once
     constexpr int NX = 3 * (SETS - 1);          // extra colour floats per entry
     constexpr int NX4 = (NX + 3) / 4;           // ... in float4 records
@@ -204,7 +198,9 @@ __device__ __forceinline__ int fwd_tile(
         bg[2] = background[2];
     }
     float sq[PPL];
-    float keep_vo[3] = {0.f, 0.f, 0.f};  // (pixels outside the image keep a zero gradient)
+    float keep_vo[PPL][3];  // (pixels outside the image keep a zero gradient)
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) keep_vo[u][0] = keep_vo[u][1] = keep_vo[u][2] = 0.f;
 #pragma unroll
     for (int u = 0; u < PPL; ++u) {
         float rr = r[u] + cv.bg_weight * bg[0];
@@ -244,9 +240,9 @@ __device__ __forceinline__ int fwd_tile(
                 dst[1] = vo[1];
                 dst[2] = vo[2];
             } else {
-                keep_vo[0] = vo[0];
-                keep_vo[1] = vo[1];
-                keep_vo[2] = vo[2];
+                keep_vo[u][0] = vo[0];
+                keep_vo[u][1] = vo[1];
+                keep_vo[u][2] = vo[2];
             }
         }
     }
@@ -260,8 +256,13 @@ __device__ __forceinline__ int fwd_tile(
         }
     }
     if (KEEP) {
-        const int lx = ((wave & 1) << 3) + (lane & 7), ly = ((wave >> 1) << 3) + (lane >> 3);
-        keep_v[ly * GI2D_BLOCK + lx] = make_float4(keep_vo[0], keep_vo[1], keep_vo[2], 0.f);
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) {
+            const int q = wave * PPL + u;
+            const int lx = ((q & 1) << 3) + (lane & 7), ly = ((q >> 1) << 3) + (lane >> 3);
+            keep_v[ly * GI2D_BLOCK + lx] =
+                make_float4(keep_vo[u][0], keep_vo[u][1], keep_vo[u][2], 0.f);
+        }
     }
     if (L2) {
         // tile sum in a fixed order whatever the variant: the lanes of a quadrant by butterfly,

@@ -112,15 +112,18 @@ def test_growing_gaussians_do_not_stop_a_fit():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,N", [("cholesky", 2500), ("rs", 2500), ("cholesky", 150),
-                                    ("cholesky", 12000)])
-def test_chained_and_one_pass_steps_are_the_plain_step(kind, N):
+@pytest.mark.parametrize("kind,N,ppl", [("cholesky", 2500, 0), ("rs", 2500, 0),
+                                        ("cholesky", 150, 0), ("cholesky", 12000, 0),
+                                        ("cholesky", 150, 4), ("rs", 2500, 4),
+                                        ("cholesky", 6000, 4)])
+def test_chained_and_one_pass_steps_are_the_plain_step(kind, N, ppl):
     """The step whose tail also projects the next iteration (3 launches), and the one that also
     runs both rasterisation passes in one kernel (2 launches), leave, bit for bit, the
     parameters, optimizer state and losses of the plain 4-launch step -- also across an outside
     modification of the parameters between two iterations, which must not be missed.  The three
     sizes give short lists (groups of lanes per entry), lists of some tens (work pieces) and
-    lists beyond one staging batch."""
+    lists beyond one staging batch; ppl = 4 forces the one-wave-per-tile kernels that sparse
+    frames get (lists of a few ids, of some tens, and of more than a wave's worth)."""
     from gaussianimage_amd.fit import FusedFitter
     H, W = 96, 112
     gt = synth.target_image(H, W).to(DEV)
@@ -128,6 +131,7 @@ def test_chained_and_one_pass_steps_are_the_plain_step(kind, N):
     for chain, one_pass in ((True, True), (True, False), (False, False)):
         torch.manual_seed(7)
         fits.append(FusedFitter(N, H, W, kind=kind, device=DEV, chain=chain, one_pass=one_pass))
+        fits[-1].ws.set_raster_ppl(ppl)
     assert fits[0].one_pass and not fits[1].one_pass
     losses = [[], [], []]
     for it in range(9):

@@ -890,3 +890,37 @@ def test_no_grad_calls_give_the_same_tensors(ops):
         assert torch.equal(img, img_grad.detach()) and torch.equal(three[0], img)
     img_grad.sum().backward()   # the recorded path is intact
     assert torch.isfinite(mg.grad).all() and torch.isfinite(cg.grad).all()
+
+
+@pytest.mark.parametrize("N,footprint", [(400, 1.0), (3000, 1.0), (9000, 1.5)])
+def test_one_wave_backward_matches_the_workgroup_backward(ops, oracle, N, footprint):
+    """The backward that gives a tile one wave (chosen by itself for sparse frames, forced here
+    through the workgroup-shape option) against the 256-lane backward and the oracle: lists of
+    a few, of some tens and of more than a wave's worth of ids."""
+    from gaussianimage_amd.pipeline import FramePipeline
+    H, W = 112, 144
+    means, L, col, op = (t.to(DEV) for t in synth.cholesky_inputs(N, seed=5, footprint=footprint))
+    op = (0.3 + 0.7 * torch.rand(N, 1, device=DEV))
+    v_img = torch.randn(H, W, 3, device=DEV)
+    grads = {}
+    for ppl in (1, 4):
+        pipe = FramePipeline(N, H, W, device=DEV, workspace=ops.Workspace(DEV))
+        pipe.ws.set_raster_ppl(ppl)
+        pipe.forward(means, L, None, col, op.reshape(-1))
+        grads[ppl] = [g.clone() for g in pipe.backward(means, L, None, col, op.reshape(-1), v_img)
+                      if g is not None]
+    for a, b in zip(grads[4], grads[1]):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale
+    xys, _, radii, conics, _ = oracle.project_cholesky_fwd(means.cpu().numpy(), L.cpu().numpy(),
+                                                           H, W)
+    offs, ids = oracle.bin_tiles(xys, radii, H, W)
+    ref = oracle.rasterize_sum_bwd(xys, conics, col.cpu().numpy(), op.cpu().numpy(), H, W, offs,
+                                   ids, v_img.cpu().numpy())
+    v_xy_ref, v_conic_ref = ref[0], ref[1]
+    v_m, v_L = oracle.project_cholesky_bwd(means.cpu().numpy(), L.cpu().numpy(), H, W, v_xy_ref,
+                                           v_conic_ref)
+    for got, want in ((grads[4][0], v_m), (grads[4][1], v_L)):
+        want = torch.from_numpy(want).to(DEV)
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got - want).abs().max()) <= 1e-4 * scale
