@@ -308,8 +308,9 @@ def bench_fused_fit(name, device, steps, concurrent=True):
     from gaussianimage_amd.fit import FusedFitter
     H, W, N, kind, fp = WORKLOADS[name]
 
-    def make():
-        f = FusedFitter(N, H, W, kind=kind, device=device, keep_image=False)
+    def make(spatial_order=False):
+        f = FusedFitter(N, H, W, kind=kind, device=device, keep_image=False,
+                        spatial_order=spatial_order)
         if fp != 1.0 and kind == "cholesky":
             bound = torch.tensor([0.5, 0.0, 0.5], device=device)
             f.params["_cholesky"].copy_((f.params["_cholesky"] + bound) * fp - bound)
@@ -328,6 +329,18 @@ def bench_fused_fit(name, device, steps, concurrent=True):
     ms = (time.perf_counter() - t0) / steps * 1e3
     out = {"fused_train_step_ms": ms, "fused_train_iters_per_s": 1e3 / ms,
            "fused_train_psnr_after_%d_iters" % (steps + 10): fit.psnr()}
+    # the same with the Gaussians kept in tile order (shared list atomics)
+    torch.manual_seed(1)
+    fit = make(spatial_order=True)
+    for _ in range(10):
+        fit.step(gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fit.step(gt)
+    torch.cuda.synchronize()
+    out["fused_train_step_ms_spatial_order"] = (time.perf_counter() - t0) / steps * 1e3
+    del fit
     if not concurrent:
         return out
     # several images fitted at once (the reference fits the images of a dataset one after the
@@ -490,6 +503,18 @@ def main():
             lambda: [pipe.rasterize(c, op) for c in three], k, 5)
         ex["bwd_only_ms"] = bench_region(
             lambda: pipe.backward(means, cov_a, cov_b, col, op, v_img), k, 5)
+        # The same Gaussians stored in the order of the tiles their centres fall in (what a
+        # fitter or an encoder that keeps a spatial order hands over): the lanes of a wave then
+        # share their list atomics.  The headline keeps the model's own random order.
+        with torch.no_grad():
+            tcol = ((0.5 * W * means[:, 0] + 0.5 * W) / 16).floor().clamp_(0, (W - 1) // 16)
+            trow = ((0.5 * H * means[:, 1] + 0.5 * H) / 16).floor().clamp_(0, (H - 1) // 16)
+            order = torch.argsort(trow * ((W + 15) // 16) + tcol, stable=True)
+            sorted_in = tuple(None if t is None else t[order].contiguous() for t in inputs)
+        pipe_s = FramePipeline(N, H, W, kind=kind, device=device)
+        run_s = pipe_s.bind(*sorted_in)
+        ex["forward_fps_spatial_order"] = 1e3 / bench_region(run_s, max(k, 100), 10)
+        del pipe_s, run_s
         # Pair evaluations per second against the fp32 vector peak: the inner loop is VALU
         # and transcendental work on cache-resident data, not HBM traffic.
         pairs = I * 256

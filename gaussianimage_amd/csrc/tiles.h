@@ -3,35 +3,105 @@
 #pragma once
 #include "common.h"
 
+// Lanes of the wave that want the same tile share one atomic.  Groups the active lanes by
+// their value of t (t < 0 = nothing to do): `leader` is the group's first lane, `rank` the
+// lane's place in the group, `gsize` the group's size.  Returning atomics are the scarce
+// resource of the list filling (about 21 G/s on the whole chip, measured, whatever the scope);
+// Gaussians that are neighbours in memory AND in the image -- a fitter or an encoder that keeps
+// them in a spatial order -- then cost one atomic per (wave, tile) instead of one per
+// (Gaussian, tile).  Lanes in no group found keep leader = themselves (a group of one): the
+// search gives up after three groups of one, which is what unordered Gaussians look like.
+__device__ __forceinline__ void group_lanes_by_tile(int t, int lane, int &leader, int &rank,
+                                                    int &gsize)
+{
+    leader = lane;
+    rank = 0;
+    gsize = 1;
+    unsigned long long todo = __ballot(t >= 0);
+    int singles = 0;
+    while (todo) {
+        const int first = (int)__builtin_ctzll(todo);
+        const int tl = __builtin_amdgcn_readlane(t, first);
+        const unsigned long long same = __ballot(t == tl);
+        const int cnt = (int)__popcll(same);
+        if (t == tl) {
+            leader = first;
+            rank = (int)__builtin_amdgcn_mbcnt_hi(
+                (unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+            gsize = cnt;
+        }
+        todo &= ~same;
+        if (cnt == 1 && ++singles == 3) break;
+    }
+}
+
 // Enters Gaussian g in the segment of every tile of its box (clipped to the band's tile rows
-// [row0,row1)).  Four returning atomics are put in flight before the first dependent store, so
-// a lane's round trips overlap instead of adding up.  Ids beyond a segment's capacity are
-// dropped; the counter keeps counting, which is how the overflow is noticed.
+// [row0,row1)).  Four rounds of returning atomics are put in flight before the first dependent
+// store, so a lane's round trips overlap instead of adding up.  Ids beyond a segment's capacity
+// are dropped; the counter keeps counting, which is how the overflow is noticed.
+// Two forms, chosen per wave: when at least four of the wave's Gaussians start in the same tile
+// (they lie in a spatial order), the lanes that enter the same tile in a round take their
+// places from one atomic; otherwise every lane walks its own box (grouping unordered Gaussians
+// would only cost instructions).  Workgroups are whole waves (lane = threadIdx.x % 64).
+#ifndef EMIT_FLIGHT
+#define EMIT_FLIGHT 4   // returning atomics a lane has in flight per round
+#endif
 __device__ __forceinline__ void emit_tiles(int g, const TileBox &box, int row0, int row1,
                                            int tiles_x, int *tile_count, int *seg, int C)
 {
+    const int lane = threadIdx.x & (WAVE - 1);
     const int y0 = max(box.y0, row0), y1 = min(box.y1, row1);
     const int w = box.x1 - box.x0;
     const int cnt = (w > 0 && y1 > y0) ? w * (y1 - y0) : 0;
     int tx = box.x0, ty = y0;
-    for (int k0 = 0; k0 < cnt; k0 += 4) {
-        int t[4], pos[4];
+    const int t_first = cnt > 0 ? (y0 - row0) * tiles_x + box.x0 : -1;
+    const unsigned long long have = __ballot(t_first >= 0);
+    if (have == 0ull) return;
+    const int t_lead = __builtin_amdgcn_readlane(t_first, (int)__builtin_ctzll(have));
+    if (__popcll(__ballot(t_first == t_lead)) < 4) {
+        for (int k0 = 0; k0 < cnt; k0 += EMIT_FLIGHT) {
+            int t[EMIT_FLIGHT], pos[EMIT_FLIGHT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < EMIT_FLIGHT; ++u) {
+                t[u] = (k0 + u < cnt) ? (ty - row0) * tiles_x + tx : -1;
+                if (++tx >= box.x1) {
+                    tx = box.x0;
+                    ++ty;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EMIT_FLIGHT; ++u) {
+                pos[u] = C;
+                if (t[u] >= 0) pos[u] = atomicAdd(&tile_count[(size_t)t[u] * CNT_STRIDE], 1);
+            }
+#pragma unroll
+            for (int u = 0; u < EMIT_FLIGHT; ++u)
+                if (pos[u] < C) seg[(size_t)t[u] * C + pos[u]] = g;
+        }
+        return;
+    }
+    for (int k0 = 0; __ballot(k0 < cnt) != 0ull; k0 += EMIT_FLIGHT) {
+        int t[EMIT_FLIGHT], pos[EMIT_FLIGHT], leader[EMIT_FLIGHT], rank[EMIT_FLIGHT], gsize[EMIT_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < EMIT_FLIGHT; ++u) {
             t[u] = (k0 + u < cnt) ? (ty - row0) * tiles_x + tx : -1;
             if (++tx >= box.x1) {
                 tx = box.x0;
                 ++ty;
             }
+            group_lanes_by_tile(t[u], lane, leader[u], rank[u], gsize[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            pos[u] = C;
-            if (t[u] >= 0) pos[u] = atomicAdd(&tile_count[(size_t)t[u] * CNT_STRIDE], 1);
+        for (int u = 0; u < EMIT_FLIGHT; ++u) {
+            pos[u] = 0;
+            if (t[u] >= 0 && leader[u] == lane)
+                pos[u] = atomicAdd(&tile_count[(size_t)t[u] * CNT_STRIDE], gsize[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (pos[u] < C) seg[(size_t)t[u] * C + pos[u]] = g;
+        for (int u = 0; u < EMIT_FLIGHT; ++u) {
+            const int p = __shfl(pos[u], leader[u]) + rank[u];
+            if (t[u] >= 0 && p < C) seg[(size_t)t[u] * C + p] = g;
+        }
     }
 }
 

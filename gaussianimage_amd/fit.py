@@ -28,7 +28,7 @@ class FusedFitter:
     def __init__(self, num_points, H, W, kind="cholesky", device="cuda:0", lr=1e-3,
                  betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0, no_prox=False,
                  lr_step=20000, lr_gamma=0.5, params=None, keep_image=True, chain=True,
-                 one_pass=True):
+                 one_pass=True, spatial_order=False):
         if kind not in ("cholesky", "rs"):
             raise ValueError("kind must be 'cholesky' or 'rs'")
         self.kind, self.N, self.H, self.W = kind, int(num_points), int(H), int(W)
@@ -50,6 +50,18 @@ class FusedFitter:
         self.names = names
         self.params = {k: params[k].detach().to(d, f32).contiguous().clone()
                        for k in names if k}
+        if spatial_order:
+            # Gaussians stored in the order of the tiles their (initial) centres fall in: the
+            # lanes of a wave then enter the same few tiles and share their list atomics.  The
+            # model does not depend on the order of its Gaussians; positions move little while
+            # fitting, so the order is set once.
+            with torch.no_grad():
+                m = torch.tanh(self.params["_xyz"])
+                col = ((0.5 * W * m[:, 0] + 0.5 * W) / BLOCK).floor().clamp_(0, (W - 1) // BLOCK)
+                row = ((0.5 * H * m[:, 1] + 0.5 * H) / BLOCK).floor().clamp_(0, (H - 1) // BLOCK)
+                order = torch.argsort(row * ((W + BLOCK - 1) // BLOCK) + col, stable=True)
+                for k in self.params:
+                    self.params[k] = self.params[k][order].contiguous()
         self._opacity = torch.ones(N, 1, dtype=f32, device=d)
         self.background = torch.ones(3, dtype=f32, device=d)  # gaussianimage_cholesky.py:38
         self.state = {k: {s: torch.zeros_like(p) for s in

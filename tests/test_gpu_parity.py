@@ -924,3 +924,38 @@ def test_one_wave_backward_matches_the_workgroup_backward(ops, oracle, N, footpr
         want = torch.from_numpy(want).to(DEV)
         scale = float(want.abs().max()) + 1e-12
         assert float((got - want).abs().max()) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("N,footprint", [(3000, 1.0), (20000, 2.0)])
+def test_spatially_ordered_gaussians_fill_the_same_lists(ops, oracle, N, footprint):
+    """Gaussians stored in a spatial order (neighbours in memory are neighbours in the image):
+    the lanes of a wave that enter the same tile then take their places from ONE atomic.  The
+    lists must come out exactly as the oracle's, through every entry point that fills them."""
+    from gaussianimage_amd.pipeline import FramePipeline
+    H, W = 176, 240
+    means, L, col, op = synth.cholesky_inputs(N, seed=11, footprint=footprint)
+    cx, cy = 0.5 * W * means[:, 0] + 0.5 * W, 0.5 * H * means[:, 1] + 0.5 * H
+    key = (cy / 16).floor() * 1000 + (cx / 16).floor()          # tile of the centre, row-major
+    order = torch.argsort(key, stable=True)
+    means, L, col, op = (t[order].contiguous().to(DEV) for t in (means, L, col, op))
+    xys_o, _, radii_o, conics_o, _ = oracle.project_cholesky_fwd(means.cpu().numpy(),
+                                                                 L.cpu().numpy(), H, W)
+    offs_o, ids_o = oracle.bin_tiles(xys_o, radii_o, H, W)
+    img_o = oracle.rasterize_sum_fwd(xys_o, conics_o, col.cpu().numpy(), op.cpu().numpy(), H, W,
+                                     offs_o, ids_o)
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    # the operator path: projection fills the lists (full radius boxes, like the oracle)
+    proj = ops.project_gaussians_2d(means, L, H, W, tb)
+    img = ops.rasterize_gaussians_sum(*proj, col, op, H, W, 16, 16)
+    offs, ids = ops.get_workspace(torch.device(DEV)).bins()
+    assert np.array_equal(offs.numpy(), offs_o) and np.array_equal(ids.numpy(), ids_o)
+    assert float((img.cpu() - torch.from_numpy(img_o)).abs().max()) <= 1e-5 * max(1.0, float(img.max()))
+    # binning from caller-made xys / radii (gi2d_bin_tiles)
+    ws = ops.Workspace(DEV)
+    ws.bin(proj[0].clone(), proj[2].clone(), H, W, force=True)
+    offs2, ids2 = ws.bins()
+    assert np.array_equal(offs2.numpy(), offs_o) and np.array_equal(ids2.numpy(), ids_o)
+    # the one-call frame (culled lists): same image bits as the operator path
+    pipe = FramePipeline(N, H, W, device=DEV, workspace=ops.Workspace(DEV))
+    assert torch.equal(pipe.forward(means, L, None, col, op.reshape(-1)), img)
+    assert torch.equal(pipe.forward(means, L, None, col, op.reshape(-1)), img)
