@@ -204,3 +204,27 @@ def test_fused_fitter_under_the_alternative_conventions():
         assert all(torch.isfinite(p).all() for p in fit.params.values())
     finally:
         ops.set_conventions(**before)
+
+
+@pytest.mark.gpu
+def test_spatial_order_is_a_permutation_of_the_same_fit():
+    """spatial_order=True stores the Gaussians in tile order (shared list atomics): the same
+    model up to a permutation, so the fit follows the same losses up to summation order."""
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N = 128, 160, 4000
+    gt = synth.target_image(H, W).to(DEV)
+    torch.manual_seed(5)
+    a = FusedFitter(N, H, W, device=DEV)
+    torch.manual_seed(5)
+    b = FusedFitter(N, H, W, device=DEV, spatial_order=True)
+    for k in a.params:   # same multiset of rows
+        assert torch.equal(torch.sort(a.params[k].sum(1)).values,
+                           torch.sort(b.params[k].sum(1)).values), k
+    m = torch.tanh(b.params["_xyz"])
+    tile = ((0.5 * H * m[:, 1] + 0.5 * H) / 16).floor() * 1000 + ((0.5 * W * m[:, 0] + 0.5 * W) / 16).floor()
+    assert bool((tile[1:] >= tile[:-1]).all())
+    for it in range(12):
+        a.step(gt)
+        b.step(gt)
+        la, lb = a.loss(), b.loss()
+        assert abs(la - lb) <= 1e-5 * la, (it, la, lb)

@@ -21,11 +21,16 @@ ap.add_argument("--width", type=int, default=1020)
 ap.add_argument("--kind", default="cholesky")
 ap.add_argument("--footprint", type=float, default=1.0,
                 help="scale of the initial Cholesky factors (3 = supports like a fitted model's)")
+ap.add_argument("--raster-ppl", type=int, default=0, choices=[0, 1, 2, 4],
+                help="workgroup shape of the rasterisers (0 = the library's choice)")
+ap.add_argument("--spatial-order", action="store_true")
 args = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(1)
 fit = FusedFitter(args.points, args.height, args.width, kind=args.kind, device=dev, lr=1e-3,
-                  keep_image=False)
+                  keep_image=False, spatial_order=args.spatial_order)
+if args.raster_ppl:
+    fit.ws.set_raster_ppl(args.raster_ppl)
 if args.footprint != 1.0 and args.kind == "cholesky":
     bound = torch.tensor([0.5, 0.0, 0.5], device=dev)
     fit.params["_cholesky"].copy_((fit.params["_cholesky"] + bound) * args.footprint - bound)
