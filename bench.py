@@ -475,7 +475,8 @@ def main():
                      "empty_event_bracket_ms": empty_bracket_ms, "valu_issue": valu},
     }
 
-    if not args.no_extras and rank == 0:
+    # (the secondary figures are single-GPU figures: the one-rank run carries them)
+    if not args.no_extras and rank == 0 and world == 1:
         ex = {}
         means, cov_a, cov_b, col, op = inputs
         v_img = torch.randn(H, W, 3, device=device)
