@@ -472,7 +472,7 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
 {
     if (!ws || (kind != 0 && kind != 1) || !gt_chw || !loss_partials || !hyper || hyper->step < 1)
         return GI2D_E_INVALID;
-    if (!xys || !depths || !radii || !conics || !num_tiles_hit) return GI2D_E_INVALID;
+    if (N > 0 && (!xys || !depths || !radii || !conics || !num_tiles_hit)) return GI2D_E_INVALID;
     if (N > 0 && (!xyz || !cov_a || (kind == 1 && !cov_b) || !features || !opacity))
         return GI2D_E_INVALID;
     if (conv && conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;

@@ -228,3 +228,25 @@ def test_spatial_order_is_a_permutation_of_the_same_fit():
         b.step(gt)
         la, lb = a.loss(), b.loss()
         assert abs(la - lb) <= 1e-5 * la, (it, la, lb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W", [(0, 40, 56), (1, 16, 16), (5, 1, 1), (300, 33, 17)])
+def test_fitter_on_degenerate_sizes(N, H, W):
+    """No Gaussians, one Gaussian, a one-pixel image, odd sizes: the fused step runs, the loss is
+    the plain step's, nothing is NaN."""
+    from gaussianimage_amd.fit import FusedFitter
+    gt = synth.target_image(H, W).to(DEV)
+    torch.manual_seed(9)
+    a = FusedFitter(N, H, W, device=DEV)
+    torch.manual_seed(9)
+    b = FusedFitter(N, H, W, device=DEV, chain=False)
+    for _ in range(4):
+        a.step(gt)
+        b.step(gt)
+        assert a.loss() == b.loss() and a.loss() == a.loss()
+    for k in a.params:
+        assert torch.equal(a.params[k], b.params[k]) and torch.isfinite(a.params[k]).all()
+    if N == 0:
+        want = float((gt.clamp(0, 1) ** 2).mean())   # an empty model renders black
+        assert abs(a.loss() - want) <= 1e-6 * max(want, 1e-12)
