@@ -125,11 +125,11 @@ def bench_forward(pipe, inputs, steps, warmup, sync_all):
     sync_all()
     t0 = time.perf_counter()
     for k in range(steps):
-        # every 4th frame is bracketed: an event pair costs the GPU ~2 us of its own
-        run(ev[k] if k % 4 == 0 else None)
+        # every 8th frame is bracketed: an event pair costs the GPU ~2 us of its own
+        run(ev[k] if k % 8 == 0 else None)
     sync_all()
     el = time.perf_counter() - t0
-    raster_ms = sorted(a.elapsed_time(b) for a, b in ev[::4])
+    raster_ms = sorted(a.elapsed_time(b) for a, b in ev[::8])
     # What an event pair measures with NOTHING between the two records, on the same busy
     # stream (outside the timed region): the bracket's own share of a bracketed launch.
     empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
