@@ -93,6 +93,31 @@ class BandGather:
         return frame[: self.H], work
 
 
+    def gather_to(self, dst=0):
+        """Collects the bands on ONE rank (a viewer, an encoder, a loss that lives on one GPU):
+        every rank sends its slot straight to ``dst`` -- point-to-point, so the seven xGMI links
+        into that GPU carry one band each at the same time, where an all-gather delivers the
+        whole frame to every rank.  Returns the ``[H,W,C]`` image view on ``dst`` and ``None``
+        elsewhere; rotates to the next slot."""
+        k = self.turn % len(self.slots)
+        slot, frame = self.slots[k], self.frames[k]
+        self.turn += 1
+        if self.world == 1:
+            frame.copy_(slot)
+            return frame[: self.H]
+        staged = _backend(self.group) == "gloo" and slot.is_cuda  # gloo gets host tensors only
+        src = slot.cpu() if staged else slot
+        if self.rank != dst:
+            dist.gather(src, dst=dst, group=self.group)
+            return None
+        dst_frame = torch.empty(frame.shape, dtype=frame.dtype) if staged else frame
+        parts = [dst_frame[r * self.slot_rows:(r + 1) * self.slot_rows] for r in range(self.world)]
+        dist.gather(src, gather_list=parts, dst=dst, group=self.group)
+        if staged:
+            frame.copy_(dst_frame)
+        return frame[: self.H]
+
+
 def all_reduce_grads(grads, group=None):
     """Sums the per-band partial parameter gradients over the ranks, in place, with a single
     collective over one flat buffer (``grads``: list of same-dtype tensors)."""
@@ -197,12 +222,19 @@ def bench_tile_row_sharded(device, rank, world, steps=50, warmup=5, workload="uh
     t_fb = timed(lambda: (frame.render_band(*inputs),
                           frame.pipe.backward(*inputs, frame.band_grad(v_image))))
     t_fb_ar = timed(lambda: (frame.render_band(*inputs), frame.backward(*inputs, v_image)))
+    # Last, so that nothing above depends on it: the frame collected on rank 0 alone
+    # (point-to-point sends instead of the all-gather).
+    try:
+        t_to0 = timed(lambda: (frame.render_band(*inputs), frame.gather.gather_to(0)))
+    except Exception:  # an exchange this backend cannot do must not cost the other figures
+        t_to0 = None
     return {"workload": f"{workload}: {W}x{H}, {N} Gaussians, tile rows split over {world} ranks",
             "band_rows": frame.gather.plan, "compute_only_ms": t_compute * 1e3,
             "compute_plus_allgather_ms": t_total * 1e3,
             "overlapped_allgather_ms": t_overlap * 1e3,
             "fps_compute_only": 1.0 / t_compute, "fps_with_allgather": 1.0 / t_total,
             "fps_overlapped": 1.0 / t_overlap, "scaling": "strong",
+            "compute_plus_gather_to_rank0_ms": None if t_to0 is None else t_to0 * 1e3,
             "allgather_bytes_per_rank": frame.gather.slot_rows * W * 3 * 4,
             "fwd_bwd_compute_only_ms": t_fb * 1e3, "fwd_bwd_plus_allreduce_ms": t_fb_ar * 1e3,
             "allreduce_bytes": 8 * N * 4}

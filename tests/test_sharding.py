@@ -55,6 +55,13 @@ def _worker(rank, world, path, H, W, N, out):
             full, _ = g.gather()
             assert full.shape == (H, W, 3)
             assert np.array_equal(full.numpy(), img * (turn + 1))
+        for turn in range(2):  # the same frame collected on one rank only
+            g.band_view().copy_(torch.from_numpy(img[y0:y1]) * (turn + 2))
+            got = g.gather_to(dst=1)
+            if rank == 1:
+                assert np.array_equal(got.numpy(), img * (turn + 2))
+            else:
+                assert got is None
         # backward: a band's partial gradients come from v_out restricted to the band
         v_out = np.random.default_rng(5).standard_normal((H, W, 3)).astype(np.float32)
         v_band = np.zeros_like(v_out)
