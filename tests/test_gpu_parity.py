@@ -959,3 +959,50 @@ def test_spatially_ordered_gaussians_fill_the_same_lists(ops, oracle, N, footpri
     pipe = FramePipeline(N, H, W, device=DEV, workspace=ops.Workspace(DEV))
     assert torch.equal(pipe.forward(means, L, None, col, op.reshape(-1)), img)
     assert torch.equal(pipe.forward(means, L, None, col, op.reshape(-1)), img)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_shapes_against_the_oracle(ops, oracle, seed):
+    """A sweep over random image sizes (down to one pixel, mostly not multiples of 16), counts,
+    footprints and opacities (some zero, some below the alpha cut): lists bit for bit, image and
+    gradients within the stated tolerances."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(1, 200)), int(rng.integers(1, 260))
+    N = int(rng.integers(1, 4000))
+    fp = float(rng.uniform(0.5, 4.0))
+    means, L, col, _ = synth.cholesky_inputs(N, seed=seed, footprint=fp)
+    op = torch.from_numpy(rng.uniform(0.0, 1.0, (N, 1)).astype(np.float32))
+    op[rng.integers(0, N, max(1, N // 10))] = 0.0
+    op[rng.integers(0, N, max(1, N // 10))] = 0.003      # below 1/255: can never contribute
+    tb = oracle.tile_bounds(H, W)
+    leaves = [means.to(DEV).requires_grad_(True), L.to(DEV).requires_grad_(True),
+              col.to(DEV).requires_grad_(True), op.to(DEV).requires_grad_(True)]
+    proj = ops.project_gaussians_2d(leaves[0], leaves[1], H, W, tb)
+    img = ops.rasterize_gaussians_sum(*proj, leaves[2], leaves[3], H, W, 16, 16)
+    offs, ids = ops.get_workspace(torch.device(DEV)).bins()
+    ref = oracle.project_cholesky_fwd(means.numpy(), L.numpy(), H, W)
+    for k in (0, 2, 3, 4):
+        assert np.array_equal(_np(proj[k]), ref[k]), k
+    r_offs, r_ids = oracle.bin_tiles(ref[0], ref[2], H, W)
+    assert np.array_equal(offs.numpy(), r_offs) and np.array_equal(ids.numpy(), r_ids)
+    r_img, margin = oracle.rasterize_sum_fwd(ref[0], ref[3], col.numpy(), op.numpy(), H, W,
+                                             r_offs, r_ids, want_margin=True)
+    ok = margin > 1e-4
+    err = np.abs(_np(img) - r_img)
+    if ok.any():
+        assert err[ok].max() <= IMG_ATOL * max(1.0, float(np.abs(r_img).max()))
+    assert err.max() <= 3.0 * (1 / 255) * max(1.0, float(col.max()))
+    # (a pair sitting on the alpha cut counts in one implementation and not in the other: such
+    # pixels -- the oracle names them -- get no image gradient, so the pair counts in neither)
+    v_out = torch.from_numpy(rng.standard_normal((H, W, 3)).astype(np.float32) * ok[..., None])
+    (img * v_out.to(DEV)).sum().backward()
+    r_bwd = oracle.rasterize_sum_bwd(ref[0], ref[3], col.numpy(), op.numpy(), H, W, r_offs, r_ids,
+                                     v_out.numpy())
+    r_m, r_L = oracle.project_cholesky_bwd(means.numpy(), L.numpy(), H, W, r_bwd[0], r_bwd[1])
+    for name, leaf, r in (("means", leaves[0], r_m), ("L", leaves[1], r_L),
+                          ("colors", leaves[2], r_bwd[2]), ("opacity", leaves[3], r_bwd[3])):
+        r = np.asarray(r).reshape(leaf.shape)
+        if np.abs(r).max() > 0:
+            assert _maxrel(_np(leaf.grad), r) <= GRAD_RTOL, (name, H, W, N, fp)
+        else:
+            assert not _np(leaf.grad).any(), name
