@@ -16,7 +16,9 @@
 #define WAVE 64
 // Workgroup size of the per-Gaussian kernels that issue scattered atomics: one wave, so that
 // the launch spreads over every CU.
+#ifndef PG_THREADS
 #define PG_THREADS 64
+#endif
 // Per-tile counters live one per 128-byte line: device-scope atomics on one line serialise at
 // the memory side, and ~48 Gaussians per tile hammering 32 neighbouring counters of one line
 // made the atomic pass three times slower.
