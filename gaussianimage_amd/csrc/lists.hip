@@ -108,6 +108,9 @@ int ensure_lists(gi2d_workspace *ws, int T, int C)
     HIP_TRY(hipMalloc(&ws->d_seg, sizeof(int) * (size_t)T * C));
     HIP_TRY(hipMemset(ws->d_count, 0, sizeof(int) * CNT_STRIDE * (size_t)T));
     HIP_TRY(hipMemset(ws->d_len, 0, sizeof(int) * (size_t)T));
+    // the clears run on the null stream, which orders nothing against a caller's non-blocking
+    // stream: finish them before anything can use the arrays
+    HIP_TRY(hipDeviceSynchronize());
     ws->tiles_cap = T;
     ws->seg_cap = C;
     ws->counters_dirty = false;
@@ -275,6 +278,7 @@ int gi2d_workspace_create(int device, gi2d_workspace **out)
     ws->device = device;
     hipError_t e = hipMalloc(&ws->d_status, sizeof(DevStatus));
     if (e == hipSuccess) e = hipMemset(ws->d_status, 0, sizeof(DevStatus));
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // (null-stream clear, see ensure_lists)
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&ws->h_status, 4 * sizeof(long long), hipHostMallocMapped);
     if (e == hipSuccess) {

@@ -176,6 +176,7 @@ int ensure_bwd_buffers(gi2d_workspace *ws, int N)
         const size_t bytes = sizeof(float) * GSLOTS * GSLOT_STRIDE * (size_t)N;
         HIP_TRY(hipMalloc(&ws->d_gslots, bytes));
         HIP_TRY(hipMemset(ws->d_gslots, 0, bytes));  // stamp 0 = never written (stamps are >= 1)
+        HIP_TRY(hipDeviceSynchronize());  // (null-stream clear: done before the caller's stream uses it)
         ws->slot_cap = N;
     }
     return GI2D_OK;
