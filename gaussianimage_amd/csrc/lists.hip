@@ -524,7 +524,9 @@ int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_
             if (e == hipSuccess)
                 e = hipMemcpyAsync(ids, d_ids, sizeof(int) * (size_t)total, hipMemcpyDefault, st);
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        // (always: the copies above read h_off and the temporaries until they complete)
+        const hipError_t e_sync = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = e_sync;
         if (d_off) (void)hipFree(d_off);
         if (d_ids) (void)hipFree(d_ids);
         if (e != hipSuccess) rc = (int)e;
