@@ -94,7 +94,7 @@ def time_cpu_oracle(name, budget_s=12.0):
             if el >= budget or n >= most:
                 return n, el
 
-    n, el = run(budget_s, 200)
+    n, el = run(budget_s, 1000)
     out = {"value": n / el, "unit": "frames/s", "cores": threads, "kind": "port",
            "sample": f"{n} forward frames of {name} (project+bin+rasterize) in {el:.1f} s; "
                      "rasterize loop OpenMP-parallel over tiles, projection and binning serial"}
