@@ -61,7 +61,8 @@ def _need_cuda(name, *tensors):
 
 def _f32c(t):
     """``t`` as a detached contiguous float32 tensor (itself when it already is one)."""
-    t = t.detach()
+    if t.requires_grad:
+        t = t.detach()
     if t.dtype is torch.float32 and t.is_contiguous():
         return t
     return t.to(torch.float32).contiguous()
@@ -168,8 +169,12 @@ _WS_LOCK = threading.Lock()
 
 
 def get_workspace(device):
-    device = torch.device(device)
+    if not isinstance(device, torch.device):
+        device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _WORKSPACES.get(idx)  # (entries are only ever added)
+    if ws is not None:
+        return ws
     with _WS_LOCK:
         ws = _WORKSPACES.get(idx)
         if ws is None:
