@@ -372,6 +372,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="kodak30k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0,
+                    help="seconds of host work spent on the CPU baseline sample")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-concurrent", action="store_true",
                     help="skip the multi-stream extras and the 4K point (overlapping kernels and "
@@ -538,7 +540,7 @@ def main():
                                   concurrent=not args.no_concurrent))
         result["extras"] = ex
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        result["cpu_baseline"] = time_cpu_oracle(args.workload)
+        result["cpu_baseline"] = time_cpu_oracle(args.workload, budget_s=args.cpu_budget_s)
         result["cpu_baseline"]["gpu_over_cpu"] = fps / result["cpu_baseline"]["value"]
 
     if distributed:
