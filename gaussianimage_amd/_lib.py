@@ -56,6 +56,17 @@ class Conv(ctypes.Structure):
                 ("bg_weight", ctypes.c_float)]
 
 
+class FrameArgs(ctypes.Structure):
+    """Mirror of ``gi2d_frame_args``."""
+    _fields_ = [("ws", ctypes.c_void_p), ("kind", ctypes.c_int)] + \
+               [(n, ctypes.c_void_p) for n in ("means2d", "cov_a", "cov_b", "colors", "opacity",
+                                               "background")] + \
+               [("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("conv", Conv)] + \
+               [(n, ctypes.c_void_p) for n in ("xys", "depths", "radii", "conics", "num_tiles_hit",
+                                               "out_img", "raster_begin_event", "raster_end_event",
+                                               "stream")]
+
+
 _vp, _i, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 _convp = ctypes.POINTER(Conv)
 
@@ -85,6 +96,7 @@ SIGNATURES = {
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_render_rs_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gi2d_render_frame": (_i, [ctypes.POINTER(FrameArgs)]),
     "gi2d_fit_backward_step_chain": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp,
                                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           ctypes.POINTER(AdanHyper), _vp]),

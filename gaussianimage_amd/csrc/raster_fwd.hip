@@ -201,6 +201,23 @@ int gi2d_render_rs_fwd(gi2d_workspace *ws, const float *means2d, const float *sc
                        background, out_img, raster_begin_event, raster_end_event, stream);
 }
 
+int gi2d_render_frame(const gi2d_frame_args *a)
+{
+    if (!a) return GI2D_E_INVALID;
+    if (a->kind == 0)
+        return gi2d_render_cholesky_fwd(a->ws, a->means2d, a->cov_a, a->colors, a->opacity,
+                                        a->background, a->N, a->H, a->W, &a->conv, a->xys,
+                                        a->depths, a->radii, a->conics, a->num_tiles_hit,
+                                        a->out_img, a->raster_begin_event, a->raster_end_event,
+                                        a->stream);
+    if (a->kind == 1)
+        return gi2d_render_rs_fwd(a->ws, a->means2d, a->cov_a, a->cov_b, a->colors, a->opacity,
+                                  a->background, a->N, a->H, a->W, &a->conv, a->xys, a->depths,
+                                  a->radii, a->conics, a->num_tiles_hit, a->out_img,
+                                  a->raster_begin_event, a->raster_end_event, a->stream);
+    return GI2D_E_INVALID;
+}
+
 int gi2d_decode_render(gi2d_workspace *ws, int kind, const gi2d_codec *codec, const float *opacity,
                        const float *background, int N, int H, int W, const gi2d_conv *conv,
                        float *xys, float *depths, int *radii, float *conics, int *num_tiles_hit,

@@ -135,25 +135,29 @@ class FramePipeline:
         returns ``run(events=None)``: the same as ``forward`` without the per-call Python work
         (for render loops over persistent buffers).  The tensors must stay alive and in place."""
         out = self.image if out is None else out
-        keep = (means, cov_a, cov_b, colors, opacity, out)
-        tail = (_ptr(colors), _ptr(opacity), _ptr(self.background), self.N, self.H, self.W,
-                ctypes.byref(self.conv), _ptr(self.xys), _ptr(self.depths), _ptr(self.radii),
-                _ptr(self.conics), _ptr(self.num_tiles_hit), _ptr(out))
-        if self.kind == "cholesky":
-            fn, head = lib.gi2d_render_cholesky_fwd, (self.ws.handle, _ptr(means), _ptr(cov_a))
-        else:
-            fn, head = lib.gi2d_render_rs_fwd, (self.ws.handle, _ptr(means), _ptr(cov_a),
-                                                _ptr(cov_b))
-        stream = _stream(self.device)
+        args = _lib.FrameArgs(
+            ws=self.ws.handle, kind=0 if self.kind == "cholesky" else 1, means2d=_ptr(means),
+            cov_a=_ptr(cov_a), cov_b=_ptr(cov_b) if self.kind != "cholesky" else None,
+            colors=_ptr(colors), opacity=_ptr(opacity), background=_ptr(self.background),
+            N=self.N, H=self.H, W=self.W, conv=self.conv, xys=_ptr(self.xys),
+            depths=_ptr(self.depths), radii=_ptr(self.radii), conics=_ptr(self.conics),
+            num_tiles_hit=_ptr(self.num_tiles_hit), out_img=_ptr(out), raster_begin_event=None,
+            raster_end_event=None, stream=_stream(self.device))
+        keep = (means, cov_a, cov_b, colors, opacity, out, args)
+        ref = ctypes.byref(args)
+        fn = lib.gi2d_render_frame
         ws, rows, name = self.ws, self.rows, "gi2d_render_%s_fwd" % self.kind
 
         def run(events=None, _keep=keep):
             if ws.rows != rows:
                 ws.set_rows(*rows)
             if events is None:
-                rc = fn(*head, *tail, None, None, stream)
+                rc = fn(ref)
             else:
-                rc = fn(*head, *tail, events[0].cuda_event, events[1].cuda_event, stream)
+                args.raster_begin_event = events[0].cuda_event
+                args.raster_end_event = events[1].cuda_event
+                rc = fn(ref)
+                args.raster_begin_event = args.raster_end_event = None
             if rc:
                 check(rc, name)
             ws.key = None

@@ -178,6 +178,28 @@ int gi2d_render_rs_fwd(gi2d_workspace *ws, const float *means2d, const float *sc
                        float *out_img, void *raster_begin_event, void *raster_end_event,
                        void *stream);
 
+/* The same call with its arguments in one struct, for render loops over
+ * persistent buffers: a host that prepares the struct once pays one pointer per
+ * frame instead of twenty arguments (through a foreign-function interface that
+ * is most of a frame's host time).  kind 0 = gi2d_render_cholesky_fwd
+ * (cov_a = L_elements, cov_b unused), kind 1 = gi2d_render_rs_fwd (cov_a =
+ * scales, cov_b = rotation).  No counterpart in the reference. */
+typedef struct gi2d_frame_args {
+    gi2d_workspace *ws;
+    int kind;
+    const float *means2d, *cov_a, *cov_b, *colors, *opacity, *background;
+    int N, H, W;
+    gi2d_conv conv;
+    float *xys, *depths;
+    int *radii;
+    float *conics;
+    int *num_tiles_hit;
+    float *out_img;
+    void *raster_begin_event, *raster_end_event; /* optional hipEvent_t */
+    void *stream;
+} gi2d_frame_args;
+int gi2d_render_frame(const gi2d_frame_args *args);
+
 /* Adan optimizer step for the parameter tensors of the fitted image, the step
  * that follows the path in every training iteration
  * (gaussianimage_cholesky.py:120 -> optimizer.py:125-235, update rule
