@@ -1006,3 +1006,31 @@ def test_random_shapes_against_the_oracle(ops, oracle, seed):
             assert _maxrel(_np(leaf.grad), r) <= GRAD_RTOL, (name, H, W, N, fp)
         else:
             assert not _np(leaf.grad).any(), name
+
+
+@pytest.mark.parametrize("kind", ["cholesky", "rs"])
+def test_bound_frame_call_equals_forward(ops, oracle, kind):
+    """FramePipeline.bind() (gi2d_render_frame, arguments in one struct) renders what forward()
+    (gi2d_render_*_fwd, twenty arguments) renders, with and without the instrumentation events."""
+    from gaussianimage_amd.pipeline import FramePipeline
+    H, W, N = 90, 130, 2000
+    if kind == "cholesky":
+        means, cov_a, col, op = (t.to(DEV) for t in synth.cholesky_inputs(N, seed=2))
+        cov_b = None
+    else:
+        means, cov_a, cov_b, col, op = (t.to(DEV) for t in synth.rs_inputs(N, seed=2))
+    op = op.reshape(-1)
+    a = FramePipeline(N, H, W, kind=kind, device=DEV, workspace=ops.Workspace(DEV))
+    b = FramePipeline(N, H, W, kind=kind, device=DEV, workspace=ops.Workspace(DEV))
+    want = a.forward(means, cov_a, cov_b, col, op).clone()
+    run = b.bind(means, cov_a, cov_b, col, op)
+    assert torch.equal(run(), want)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    for e in ev:
+        e.record()
+    assert torch.equal(run(ev), want)
+    torch.cuda.synchronize()
+    assert ev[0].elapsed_time(ev[1]) > 0
+    assert torch.equal(run(), want)
+    for x, y in ((a.xys, b.xys), (a.radii, b.radii), (a.conics, b.conics)):
+        assert torch.equal(x, y)
