@@ -488,6 +488,9 @@ def main():
             pipe.backward(means, cov_a, cov_b, col, op, v_img)
 
         k = max(20, args.steps // 2)
+        # the headline loop without its event brackets (each bracketed frame costs ~6 us more)
+        run_plain = pipe.bind(means, cov_a, cov_b, col, op)
+        ex["forward_fps_no_event_brackets"] = 1e3 / bench_region(run_plain, max(args.steps, 100), 10)
         ex["fwd_bwd_ms"] = bench_region(fwd_bwd, k, 5)
         ex["project_ms"] = bench_region(lambda: pipe.project(means, cov_a, cov_b), k, 5)
         pipe.project(means, cov_a, cov_b)
