@@ -1034,3 +1034,27 @@ def test_bound_frame_call_equals_forward(ops, oracle, kind):
     assert torch.equal(run(), want)
     for x, y in ((a.xys, b.xys), (a.radii, b.radii), (a.conics, b.conics)):
         assert torch.equal(x, y)
+
+
+def test_overflow_with_shared_atomics_is_reported_and_repaired(ops, oracle):
+    """Spatially ordered Gaussians (lanes share list atomics) against a capacity that is too
+    small: the overflow is reported, never written past a segment, and the grown workspace bins
+    exactly."""
+    from gaussianimage_amd import _lib
+    H, W, N = 64, 96, 6000
+    means, L, col, op = synth.cholesky_inputs(N, seed=8, footprint=2.0)
+    key = ((0.5 * H * means[:, 1] + 0.5 * H) / 16).floor() * 100 + ((0.5 * W * means[:, 0] + 0.5 * W) / 16).floor()
+    order = torch.argsort(key, stable=True)
+    means, L = means[order].contiguous(), L[order].contiguous()
+    tb = oracle.tile_bounds(H, W)
+    ws = ops.Workspace(DEV)
+    ws.reserve(64, 24)
+    proj = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+    with pytest.raises(_lib.Gi2dError) as ei:
+        ws.bin(proj[0], proj[2], H, W, flags=_lib.BIN_SYNC | _lib.BIN_NOGROW, force=True)
+    assert ei.value.status == _lib.GI2D_E_CAPACITY
+    ws.bin(proj[0], proj[2], H, W, flags=_lib.BIN_SYNC, force=True)
+    offs, ids = ws.bins()
+    r_offs, r_ids = oracle.bin_tiles(_np(proj[0]), _np(proj[2]), H, W)
+    assert np.diff(r_offs).max() > 64
+    assert np.array_equal(ids.numpy(), r_ids) and np.array_equal(offs.numpy(), r_offs)
