@@ -280,6 +280,10 @@ def bench_concurrent(name, inputs, device, steps, streams=4):
             for _ in range(5):
                 run()
         runs.append(run)
+    # (the first few hundred overlapping launches of a process run well below the steady rate:
+    # warm the streams up together, not only one by one)
+    for k in range(400):
+        runs[k % streams]()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
@@ -289,7 +293,7 @@ def bench_concurrent(name, inputs, device, steps, streams=4):
     # the same for ONE caller through the packaged ring (two frames in flight)
     from gaussianimage_amd.pipeline import FrameRing
     ring = FrameRing(N, H, W, kind=kind, device=device, depth=2)
-    for _ in range(10):
+    for _ in range(200):
         ring.render(*inputs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
