@@ -110,6 +110,24 @@ def time_cpu_oracle(name, budget_s=12.0):
     return out
 
 
+class no_gc:
+    """Timed regions run with Python's cyclic garbage collector off (and a collection done up
+    front): with torch imported a full collection takes several milliseconds -- longer than a
+    whole timed region here -- and when one happens to fall into a region is a matter of the
+    interpreter's allocation counters, not of the code being measured."""
+
+    def __enter__(self):
+        import gc
+        self.was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was_enabled:
+            gc.enable()
+
+
 def bench_forward(pipe, inputs, steps, warmup, sync_all):
     """K forward frames, one C call each (gi2d_render_*_fwd).  The rasterize launch of every
     timed frame is bracketed by HIP events recorded inside that call on the launch stream."""
@@ -122,13 +140,14 @@ def bench_forward(pipe, inputs, steps, warmup, sync_all):
     run = pipe.bind(means, cov_a, cov_b, col, op)
     for _ in range(warmup):
         run()
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        # every 8th frame is bracketed: an event pair costs the GPU ~2 us of its own
-        run(ev[k] if k % 8 == 0 else None)
-    sync_all()
-    el = time.perf_counter() - t0
+    with no_gc():
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            # every 8th frame is bracketed: an event pair costs the GPU ~2 us of its own
+            run(ev[k] if k % 8 == 0 else None)
+        sync_all()
+        el = time.perf_counter() - t0
     raster_ms = sorted(a.elapsed_time(b) for a, b in ev[::8])
     # What an event pair measures with NOTHING between the two records, on the same busy
     # stream (outside the timed region): the bracket's own share of a bracketed launch.
@@ -146,12 +165,13 @@ def bench_forward(pipe, inputs, steps, warmup, sync_all):
 def bench_region(fn, steps, warmup):
     for _ in range(warmup):
         fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    with no_gc():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
 
 
 def bench_model_loops(name, device, steps):
@@ -284,23 +304,27 @@ def bench_concurrent(name, inputs, device, steps, streams=4):
     # warm the streams up together, not only one by one)
     for k in range(400):
         runs[k % streams]()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        runs[k % streams]()
-    torch.cuda.synchronize()
-    out = {"fps_%d_streams" % streams: steps / (time.perf_counter() - t0)}
+    with no_gc():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            runs[k % streams]()
+        torch.cuda.synchronize()
+        out = {"fps_%d_streams" % streams: steps / (time.perf_counter() - t0)}
     # the same for ONE caller through the packaged ring (two frames in flight)
     from gaussianimage_amd.pipeline import FrameRing
-    ring = FrameRing(N, H, W, kind=kind, device=device, depth=2)
-    for _ in range(200):
-        ring.render(*inputs)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ring.render(*inputs, wait_inputs=False)
-    torch.cuda.synchronize()
-    out["fps_frame_ring_depth2"] = steps / (time.perf_counter() - t0)
+    for depth in (2, 4):
+        ring = FrameRing(N, H, W, kind=kind, device=device, depth=depth)
+        for _ in range(200):
+            ring.render(*inputs)
+        with no_gc():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ring.render(*inputs, wait_inputs=False)
+            torch.cuda.synchronize()
+            out["fps_frame_ring_depth%d" % depth] = steps / (time.perf_counter() - t0)
+        del ring
     return out
 
 
@@ -415,6 +439,9 @@ def main():
 
     from gaussianimage_amd.pipeline import FramePipeline
 
+    # every measurement below runs with the cyclic garbage collector off (see no_gc); the
+    # process is short-lived
+    no_gc().__enter__()
     H, W, N, kind, fp = WORKLOADS[args.workload]
     inputs = make_inputs(args.workload, device, seed=1 + rank)
     pipe = FramePipeline(N, H, W, kind=kind, device=device)
