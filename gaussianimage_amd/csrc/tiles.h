@@ -43,6 +43,10 @@ __device__ __forceinline__ void group_lanes_by_tile(int t, int lane, int &leader
 // (they lie in a spatial order), the lanes that enter the same tile in a round take their
 // places from one atomic; otherwise every lane walks its own box (grouping unordered Gaussians
 // would only cost instructions).  Workgroups are whole waves (lane = threadIdx.x % 64).
+// lanes of a wave that must start in the same tile for the wave to share its list atomics
+#ifndef EMIT_GROUP_MIN
+#define EMIT_GROUP_MIN 4
+#endif
 #ifndef EMIT_FLIGHT
 #define EMIT_FLIGHT 4   // returning atomics a lane has in flight per round
 #endif
@@ -58,7 +62,7 @@ __device__ __forceinline__ void emit_tiles(int g, const TileBox &box, int row0, 
     const unsigned long long have = __ballot(t_first >= 0);
     if (have == 0ull) return;
     const int t_lead = __builtin_amdgcn_readlane(t_first, (int)__builtin_ctzll(have));
-    if (__popcll(__ballot(t_first == t_lead)) < 4) {
+    if (__popcll(__ballot(t_first == t_lead)) < EMIT_GROUP_MIN) {
         for (int k0 = 0; k0 < cnt; k0 += EMIT_FLIGHT) {
             int t[EMIT_FLIGHT], pos[EMIT_FLIGHT];
 #pragma unroll
