@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
 def make_inputs(name, device, seed=1):
-    from gaussianimage_amd import synth
+    from gaussianimage_amd._testing import synth
     H, W, N, kind, fp = WORKLOADS[name]
     if kind == "cholesky":
         means, L, col, op = synth.cholesky_inputs(N, seed=seed, footprint=fp)
@@ -63,7 +63,7 @@ def algorithmic_bytes_raster(I, P, T):
 
 def time_cpu_oracle(name, budget_s=12.0):
     """CPU baseline: this repository's C restatement (oracle) of the same forward path."""
-    from gaussianimage_amd import synth
+    from gaussianimage_amd._testing import synth
     threads = min(16, os.cpu_count() or 1)
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     threads = int(os.environ["OMP_NUM_THREADS"])
@@ -175,12 +175,12 @@ def bench_region(fn, steps, warmup):
 
 
 def bench_model_loops(name, device, steps):
-    """The reference's own two loops on a stand-in of its model (gaussianimage_amd/harness.py),
+    """The reference's own two loops on a stand-in of its model (gaussianimage_amd/_testing/harness.py),
     through the drop-in operators: train_iter (forward, L2 loss, backward, PSNR .item(), Adan
     step, StepLR -- /root/reference/train.py:141-145) and the FPS loop (100 x model() under
     eval + no_grad, wall clock -- /root/reference/train.py:242-249; synchronised at both ends
     here)."""
-    from gaussianimage_amd import harness, synth
+    from gaussianimage_amd._testing import harness, synth
     H, W, N, kind, _ = WORKLOADS[name]
     torch.manual_seed(1)
     if kind == "cholesky":
@@ -332,7 +332,7 @@ def bench_fused_fit(name, device, steps, concurrent=True):
     """The fused fitting iteration (gaussianimage_amd/fit.py): forward, L2 loss, backward and
     Adan step in two launches on the raw parameters, no host synchronisation inside the loop.
     The workload's footprint scales the initial Cholesky factors as it does the forward inputs."""
-    from gaussianimage_amd import synth
+    from gaussianimage_amd._testing import synth
     from gaussianimage_amd.fit import FusedFitter
     H, W, N, kind, fp = WORKLOADS[name]
 

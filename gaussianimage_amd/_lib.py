@@ -27,6 +27,7 @@ BIN_NOGROW = 4
 OPT_CULL = 1
 OPT_RASTER_PPL = 2
 OPT_DROP_PENDING = 3
+OPT_BWD_SERIAL = 4
 
 BLOCK = 16
 MAX_COLOR_SETS = 3  # GI2D_MAX_COLOR_SETS

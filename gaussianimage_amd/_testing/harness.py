@@ -18,9 +18,9 @@ from gsplat.project_gaussians_2d import project_gaussians_2d
 from gsplat.project_gaussians_2d_scale_rot import project_gaussians_2d_scale_rot
 from gsplat.rasterize_sum import rasterize_gaussians_sum
 
-from .ops import rasterize_gaussians_sum_multi
+from ..ops import rasterize_gaussians_sum_multi
 
-from .adan import Adan
+from ..adan import Adan
 
 
 class _Base(nn.Module):

@@ -154,7 +154,7 @@ def synthetic_encoding(num_points, kind="cholesky", seed=0, footprint=1.0, bits=
     (/root/reference/gaussianimage_cholesky.py:47-49, gaussianimage_rs.py:39-42: 6-bit uniform
     quantisers, 2-layer residual VQ with 8 code vectors of dimension 3), drawn from the models'
     initial parameter distributions.  Returns ``(encoding, quantizers)`` of CPU tensors."""
-    from . import synth
+    from ._testing import synth
     g = torch.Generator().manual_seed(seed)
     qmax = 2 ** bits - 1
     xyz = torch.atanh(2 * (torch.rand(num_points, 2, generator=g) - 0.5).clamp(-0.4999, 0.4999))

@@ -13,6 +13,10 @@
 #include "../../include/gi2d.h"
 #pragma GCC visibility pop
 
+// sine / cosine as a fixed IEEE operation sequence shared with the CPU checker
+#define GI2D_SINCOS_FN __device__ __forceinline__
+#include "sincos_f32.h"
+
 #define WAVE 64
 // Workgroup size of the per-Gaussian kernels that issue scattered atomics: one wave, so that
 // the launch spreads over every CU.
@@ -27,7 +31,7 @@
 #define PART_STRIDE 9  // backward partial sums per (tile, Gaussian): v_xy 2, v_conic 3, v_rgb 3, v_op 1
 // Backward pass 1 leaves the partial sums of a Gaussian's first GSLOTS tiles (row-major in its
 // tile box) in the Gaussian's OWN slots, GSLOT_STRIDE floats each: the 9 sums and the stamp of
-// the binning they belong to.  Pass 2 reads the first GSLOTS_EAGER of them before it knows
+// the backward pass that wrote them.  Pass 2 reads the first GSLOTS_EAGER of them before it knows
 // anything about the Gaussian (boxes at initialisation are mostly <= 2x2), the others once the
 // box is known (fitted Gaussians cover 3x3 .. 4x4 tiles) -- no look-up either way; only tiles
 // beyond GSLOTS go through the per-tile slab and a search in the tile's list.

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
         const float sg = 1.0f / (1.0f + expf(-c2.p));
         const float theta = sg * 2.0f * 3.14159274f;
         float sn, cs;
-        sincosf(theta, &sn, &cs);
+        gi2d_sincos_f32(theta, &sn, &cs);
         const float q1 = s1 * s1, q2 = s2 * s2;
         if (cov_to_conic_radius(cs * cs * q1 + sn * sn * q2, cs * sn * (q1 - q2),
                                 sn * sn * q1 + cs * cs * q2, a, b, c, radius)) {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
             const float s1 = fabsf(nc0 + 0.5f), s2 = fabsf(nc1 + 0.5f);
             const float theta = (1.0f / (1.0f + expf(-nc2))) * 2.0f * 3.14159274f;
             float s, c;
-            sincosf(theta, &s, &c);
+            gi2d_sincos_f32(theta, &s, &c);
             const float q1 = s1 * s1, q2 = s2 * s2;
             sxx = c * c * q1 + s * s * q2;
             sxy = c * s * (q1 - q2);
@@ -213,7 +213,7 @@ fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *
                   int row0, int T, gi2d_conv cv, int cull, DevStatus *status,
                   long long generation, float *__restrict__ out, const float *__restrict__ gt,
                   float *__restrict__ loss_part, float *__restrict__ partials,
-                  float *__restrict__ gslots, size_t gslot_n)
+                  float *__restrict__ gslots, size_t gslot_n, int stamp)
 {
     static_assert(PPL == 1 || PPL == 4, "unsupported variant");
     constexpr int NT = 256 / PPL;
@@ -246,7 +246,6 @@ fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *
         gid_first = s_sorted[tid];
     else
         gid_first = tid < min(C, min(NT, BWD_BATCH)) ? lst[tid] : 0;
-    const int stamp = (int)generation;
     if (PPL == 1)
         fit_bwd_256(pool, s_v, s_w, lst, gid_first, n_raw, slot0, tx, ty, xys, radii, conics,
                     colors, opacity, H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots,
@@ -418,7 +417,7 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
     int *radii_io = chained ? chain->radii : const_cast<int *>(radii);
 #define GI2D_TAIL_ARGS Tn, h, xys_io, radii_io, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, \
                        ws->bin_row1, ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials,          \
-                       ws->d_gslots, (size_t)ws->slot_cap, (int)ws->generation, ch
+                       ws->d_gslots, (size_t)ws->slot_cap, ws->bwd_stamp, ch
     // one wave per workgroup when the lanes also issue the list-filling atomics, so that the
     // launch spreads over every CU (as in the projection kernels)
     const int threads = chained ? PG_THREADS : 256;
@@ -491,11 +490,13 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
     hipStream_t st = (hipStream_t)stream;
     rc = ensure_bwd_buffers(ws, N);
     if (rc != GI2D_OK) return rc;
+    rc = next_bwd_stamp(ws, st);
+    if (rc != GI2D_OK) return rc;
 #define GI2D_FIT_RASTER_ARGS ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, \
                              features, opacity, background, H, W, ws->tiles_x, ws->tiles_y,      \
                              ws->bin_row0, T, *conv, ws->cull, ws->d_status, ws->generation,     \
                              image, gt_chw, loss_partials, ws->d_partials, ws->d_gslots,         \
-                             (size_t)ws->slot_cap
+                             (size_t)ws->slot_cap, ws->bwd_stamp
     const bool one_wave = sparse_frame(ws, T);
     if (ws->lists_raw) {
         if (one_wave) fit_raster_kernel<true, 4><<<T, 64, 0, st>>>(GI2D_FIT_RASTER_ARGS);

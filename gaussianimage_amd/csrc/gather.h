@@ -5,7 +5,7 @@
 // Adds up Gaussian g's partial sums in the row-major order of its tile box.  The first GSLOTS
 // tiles come from the Gaussian's own slots -- GSLOTS_EAGER of them loaded before anything else
 // is known about it (one round trip), the rest once the box is known; a slot counts only if its
-// stamp is this binning's (an overflowed or unreachable tile writes none).  Larger boxes: the
+// stamp is this backward pass's (an overflowed or unreachable tile writes none).  Larger boxes: the
 // remaining tiles by binary search in the tile's sorted list.
 __device__ __forceinline__ void gather_partials(int g, int r, float cx, float cy, int tiles_x,
                                                 int tiles_y, int row0, int row1,

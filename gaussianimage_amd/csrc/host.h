@@ -19,6 +19,8 @@ struct gi2d_workspace {
     long long *h_status_dev = nullptr;
     int64_t generation = 0;
     int64_t overflow_ack = 0;
+    int64_t bwd_serial = 0;     // backward pass-1 launches so far
+    int bwd_stamp = 0;          // stamp of the latest one (1 .. INT_MAX), 0 = none yet
     int tiles_x = 0, tiles_y = 0, n_binned = 0;
     int row0 = 0, row1 = INT_MAX;    // tile rows requested by the caller (a band)
     int bin_row0 = 0, bin_row1 = 0;  // tile rows of the current lists
@@ -124,6 +126,7 @@ int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *conics, c
 
 // raster_bwd.hip
 int ensure_bwd_buffers(gi2d_workspace *ws, int N);
+int next_bwd_stamp(gi2d_workspace *ws, hipStream_t st);
 int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii, const float *conics,
                      const float *colors, const float *opacity, int N, int H, int W,
                      const gi2d_conv *conv, const float *v_out, hipStream_t st);

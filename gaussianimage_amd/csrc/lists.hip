@@ -332,6 +332,10 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
         case GI2D_OPT_DROP_PENDING:
             ws->chain_pending = false;
             return GI2D_OK;
+        case GI2D_OPT_BWD_SERIAL:
+            if (value < 0) return GI2D_E_INVALID;
+            ws->bwd_serial = value;
+            return GI2D_OK;
         default: return GI2D_E_INVALID;
     }
 }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
         theta = (1.0f / (1.0f + expf(-theta))) * 2.0f * 3.14159274f;
     }
     float s, c;
-    sincosf(theta, &s, &c);
+    gi2d_sincos_f32(theta, &s, &c);
     float q1 = s1 * s1, q2 = s2 * s2;
     float sxx = c * c * q1 + s * s * q2;
     float sxy = c * s * (q1 - q2);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void project_decode_fwd_kernel(
     float sxx, sxy, syy;
     if (RS) {
         float s, c;
-        sincosf(d.b0, &s, &c);
+        gi2d_sincos_f32(d.b0, &s, &c);
         const float q1 = d.a0 * d.a0, q2 = d.a1 * d.a1;
         sxx = c * c * q1 + s * s * q2;
         sxy = c * s * (q1 - q2);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void project_rs_bwd_kernel(
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     float s, c;
-    sincosf(rot[g], &s, &c);
+    gi2d_sincos_f32(rot[g], &s, &c);
     float s1 = scales[2 * g], s2 = scales[2 * g + 1];
     float q1 = s1 * s1, q2 = s2 * s2;
     float sxx = c * c * q1 + s * s * q2;

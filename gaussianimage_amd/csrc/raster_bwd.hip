@@ -182,6 +182,30 @@ int ensure_bwd_buffers(gi2d_workspace *ws, int N)
     return GI2D_OK;
 }
 
+__global__ __launch_bounds__(256) void zero_floats_kernel(float *p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        p[i] = 0.f;
+}
+
+// Every backward pass 1 gets a stamp of its own, which its partial sums carry in the Gaussians'
+// slots and which pass 2 asks for: an entry whose support misses a tile writes nothing there,
+// and whatever an EARLIER pass left in that slot -- of another frame, or of the same binning
+// with other opacities or conics -- must not count.  Stamps run 1 .. INT_MAX; before they start
+// over, the slots are cleared (stamp 0 = never written).  Call after ensure_bwd_buffers.
+int next_bwd_stamp(gi2d_workspace *ws, hipStream_t st)
+{
+    ws->bwd_serial += 1;
+    ws->bwd_stamp = (int)((ws->bwd_serial - 1) % (int64_t)INT_MAX) + 1;
+    if (ws->bwd_stamp == 1 && ws->bwd_serial > 1 && ws->slot_cap > 0) {
+        const size_t n = (size_t)GSLOTS * GSLOT_STRIDE * (size_t)ws->slot_cap;
+        zero_floats_kernel<<<2048, 256, 0, st>>>(ws->d_gslots, n);
+        return launch_status();
+    }
+    return GI2D_OK;
+}
+
 // Backward pass 1 (per-tile partial sums into the slab); shared by the operator backward and
 // the fused fitting step.
 int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
@@ -193,12 +217,14 @@ int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
     if (rc != GI2D_OK) return rc;
     rc = ensure_bwd_buffers(ws, N);
     if (rc != GI2D_OK) return rc;
+    rc = next_bwd_stamp(ws, st);
+    if (rc != GI2D_OK) return rc;
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (T > 0) {
 #define GI2D_BWD_ARGS ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, colors, opacity, H, W, \
                       ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull,     \
                       v_out, ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap,                   \
-                      (int)ws->generation
+                      ws->bwd_stamp
         if (sparse_frame(ws, T))
             rasterize_sum_bwd_wave_kernel<<<T, 64, 0, st>>>(GI2D_BWD_ARGS);
         else
@@ -230,7 +256,7 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
     if (rc != GI2D_OK) return rc;
     gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(
         xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, ws->d_len, ws->d_seg,
-        ws->seg_cap, ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap, (int)ws->generation, v_xys,
+        ws->seg_cap, ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap, ws->bwd_stamp, v_xys,
         v_conics, v_colors, v_opacity);
     return launch_status();
 }

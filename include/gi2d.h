@@ -80,6 +80,10 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
  * next gi2d_fit_forward projects again.  For callers that change the
  * parameters themselves between two iterations. */
 #define GI2D_OPT_DROP_PENDING 3
+/* GI2D_OPT_BWD_SERIAL (testing aid): positions the counter of backward launches, from which
+ * the stamps of the backward's partial sums derive (1 .. INT_MAX, then the slots are cleared
+ * and the stamps start over), so that a test can cross the wrap. */
+#define GI2D_OPT_BWD_SERIAL 4
 int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value);
 /* Tile-row band: binning and rasterisation cover tile rows [row_begin,row_end)
  * of the frame only (row_end is clipped to the frame); out_img / v_out then

@@ -166,3 +166,11 @@ def render_cholesky(means, L, colors, H, W, opacity=None, conv=None):
     if opacity is None:
         opacity = np.ones((xys.shape[0], 1), np.float32)
     return rasterize_sum_fwd(xys, conics, colors, opacity, H, W, offs, ids, conv=conv)
+
+
+def sincos_f32(theta):
+    """The shared fixed-sequence sine / cosine (csrc/sincos_f32.h) on a float32 array."""
+    theta = _f(theta).reshape(-1)
+    s, c = np.empty_like(theta), np.empty_like(theta)
+    lib().oracle_sincos_f32(theta.size, _p(theta), _p(s), _p(c))
+    return s, c

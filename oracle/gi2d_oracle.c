@@ -30,6 +30,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Sine and cosine of the rotation-scale projection: the product's own header, included as text.
+ * The integer outputs (radius, tile box) hinge on the last bits of sin/cos, and libm's differ
+ * from the device library's; both sides therefore evaluate this one fixed sequence of IEEE
+ * operations.  tests/test_oracle.py checks it against libm's double-precision functions. */
+#include "../gaussianimage_amd/csrc/sincos_f32.h"
+
 #define GI2D_BLOCK 16
 
 typedef struct {
@@ -142,7 +148,8 @@ void oracle_project_rs_fwd(int N, const float *means, const float *scales, const
                            float *depths, int *radii, float *conics, int *num_tiles_hit)
 {
     for (int g = 0; g < N; ++g) {
-        float c = cosf(rot[g]), s = sinf(rot[g]);
+        float c, s;
+        gi2d_sincos_f32(rot[g], &s, &c);
         float s1 = scales[2 * g], s2 = scales[2 * g + 1];
         float q1 = s1 * s1, q2 = s2 * s2;
         float sxx = c * c * q1 + s * s * q2;
@@ -308,6 +315,12 @@ void oracle_rasterize_sum_bwd(int N, const float *xys, const float *conics, cons
     free(acc);
 }
 
+/* The shared sine / cosine, exported for the tests. */
+void oracle_sincos_f32(int n, const float *theta, float *s, float *c)
+{
+    for (int i = 0; i < n; ++i) gi2d_sincos_f32(theta[i], s + i, c + i);
+}
+
 /* Gradient of the covariance from the gradient of its inverse (the conic):
  * with V = [[va, vb/2],[vb/2, vc]] and C = Sigma^-1, dL/dSigma = -C V C.
  * Returned as (gxx, gxy, gyy) where gxy is the derivative with respect to the
@@ -368,7 +381,8 @@ void oracle_project_rs_bwd(int N, const float *means, const float *scales, const
         v_means[2 * g] = v_means[2 * g + 1] = 0.0f;
         v_scales[2 * g] = v_scales[2 * g + 1] = 0.0f;
         v_rot[g] = 0.0f;
-        float cf = cosf(rot[g]), sf = sinf(rot[g]);
+        float cf, sf;
+        gi2d_sincos_f32(rot[g], &sf, &cf);
         float s1f = scales[2 * g], s2f = scales[2 * g + 1];
         float q1f = s1f * s1f, q2f = s2f * s2f;
         if (!bwd_active(cf * cf * q1f + sf * sf * q2f, cf * sf * (q1f - q2f),

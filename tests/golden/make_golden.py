@@ -18,7 +18,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from gaussianimage_amd import synth  # noqa: E402
+from gaussianimage_amd._testing import synth  # noqa: E402
 from oracle import cport, torch_oracle as to  # noqa: E402
 
 CASES = [(48, 64, 64, 0), (48, 64, 512, 1), (80, 96, 64, 2), (80, 96, 512, 0)]
@@ -30,11 +30,13 @@ def make(kind, H, W, N, seed):
         raw = synth.cholesky_params(N, seed=seed)
         fwd = to.model_forward_cholesky
         means, L, col, op = synth.cholesky_inputs(N, seed=seed)
+        op_in = (means, L)
         proj = cport.project_cholesky_fwd(means.numpy(), L.numpy(), H, W)
     else:
         raw = synth.rs_params(N, seed=seed)
         fwd = to.model_forward_rs
         means, sc, rot, col, op = synth.rs_inputs(N, seed=seed)
+        op_in = (means, sc, rot)
         proj = cport.project_rs_fwd(means.numpy(), sc.numpy(), rot.numpy(), H, W)
     leaves = [p.double().requires_grad_(True) for p in raw]
     img = fwd(*leaves, H, W)
@@ -48,6 +50,11 @@ def make(kind, H, W, N, seed):
          "render64": img.detach().numpy().astype(np.float32), "loss64": loss.item(),
          "xys": xys, "radii": radii, "conics": conics, "num_tiles_hit": nth,
          "tile_offsets": offs, "ids": ids, "image": out, "margin": margin}
+    # the activated operator inputs exactly as the C restatement received them: the GPU test
+    # feeds these bits to the projection and asks for bit-equal outputs (activations computed
+    # on another device or CPU differ in their last bits, which is not the projection's doing)
+    for i, t in enumerate(op_in):
+        d[f"in{i}"] = t.numpy()
     for i, (p, leaf) in enumerate(zip(raw, leaves)):
         d[f"param{i}"] = p.numpy()
         d[f"grad{i}"] = leaf.grad.numpy().astype(np.float32)

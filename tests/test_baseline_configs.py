@@ -1,0 +1,153 @@
+"""The BASELINE configurations at their full sizes on the GPU.
+
+config 3: rotation-scale covariance, 768x512, 30 000 Gaussians -- forward AND backward against
+          the oracle (projection outputs and tile lists bit for bit, image to 1e-5, every
+          gradient element-wise);
+config 4: ~1020x768, 50 000 Gaussians, the fitting loop -- the fused two-launch step against
+          its four-launch form (bits), against reference-style training through the drop-in
+          operators (tolerance), and its first loss against the oracle;
+config 5: 3840x2160, 200 000 Gaussians split by tile rows over 2 / 4 / 8 ranks -- every band,
+          rendered in turn on this one device, is bit-identical to the unsharded frame and the
+          per-band gradients sum to the unsharded gradients.
+(config 2 full size: tests/test_gpu_parity.py::test_baseline_config_full_size.)
+"""
+import numpy as np
+import pytest
+import torch
+
+from gaussianimage_amd._testing import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _assert_grad(got, ref, name, rtol=1e-4, floor=2e-6):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    m = max(np.abs(ref).max(), 1e-30)
+    assert np.abs(got - ref).max() <= rtol * m, name
+    assert (np.abs(got - ref) <= rtol * np.abs(ref) + floor * m).all(), (name, "element-wise")
+
+
+def test_config3_rs_forward_and_backward_against_the_oracle(oracle):
+    from gaussianimage_amd import ops
+    H, W, N = 512, 768, 30000
+    means, sc, rot, col, op = synth.rs_inputs(N, seed=1)
+    tb = oracle.tile_bounds(H, W)
+    m, s, r = (t.to(DEV).requires_grad_(True) for t in (means, sc, rot))
+    c = col.to(DEV).requires_grad_(True)
+    xys, depths, radii, conics, nth = ops.project_gaussians_2d_scale_rot(m, s, r, H, W, tb)
+    ref = oracle.project_rs_fwd(means.numpy(), sc.numpy(), rot.numpy(), H, W)
+    for got, want, name in zip((xys, depths, radii, conics, nth), ref,
+                               ("xys", "depths", "radii", "conics", "num_tiles_hit")):
+        assert np.array_equal(_np(got), want), name
+    opa = torch.ones(N, 1, device=DEV)
+    # leaves between the two operators, so that the rasteriser's own gradients are seen too
+    xys_l, con_l = xys.detach().requires_grad_(True), conics.detach().requires_grad_(True)
+    img = ops.rasterize_gaussians_sum(xys_l, depths, radii, con_l, nth, c, opa, H, W, 16, 16)
+    v_out = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(5))
+    (img * v_out.to(DEV)).sum().backward()
+    offs, ids = oracle.bin_tiles(ref[0], ref[2], H, W)
+    g_offs, g_ids = ops.get_workspace(DEV).bins()
+    assert np.array_equal(g_offs.numpy(), offs) and np.array_equal(g_ids.numpy(), ids)
+    want, margin = oracle.rasterize_sum_fwd(ref[0], ref[3], col.numpy(), np.ones((N, 1)), H, W,
+                                            offs, ids, want_margin=True)
+    ok = margin > 1e-4
+    assert ok.mean() > 0.995
+    assert np.abs(_np(img) - want)[ok].max() <= 1e-5
+    rg = oracle.rasterize_sum_bwd(ref[0], ref[3], col.numpy(), np.ones((N, 1)), H, W, offs, ids,
+                                  v_out.numpy())
+    _assert_grad(_np(xys_l.grad), rg[0], "v_xys")
+    _assert_grad(_np(con_l.grad), rg[1], "v_conics")
+    _assert_grad(_np(c.grad), rg[2], "v_colors")
+    # ... and on through the projection's backward to means, scales and rotation
+    torch.autograd.backward([xys, conics], [xys_l.grad, con_l.grad])
+    pm, ps, pr = oracle.project_rs_bwd(means.numpy(), sc.numpy(), rot.numpy(), H, W,
+                                       _np(xys_l.grad), _np(con_l.grad))
+    _assert_grad(_np(m.grad), pm, "v_means")
+    _assert_grad(_np(s.grad), ps, "v_scales")
+    _assert_grad(_np(r.grad), pr, "v_rotation")
+
+
+def test_config4_fused_fit_at_full_size(oracle):
+    from gaussianimage_amd._testing import harness
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N = 768, 1020, 50000
+    gt = synth.target_image(H, W).to(DEV)
+    xyz, chol, feat = synth.cholesky_params(N, seed=1)
+    params = {"_xyz": xyz, "_cholesky": chol, "_features_dc": feat}
+    fused = FusedFitter(N, H, W, device=DEV, params=params)
+    plain = FusedFitter(N, H, W, device=DEV, params=params, chain=False, one_pass=False)
+    assert fused.one_pass and not plain.chain
+    # first loss against the oracle's forward of the same parameters
+    means, L, col, op = synth.cholesky_inputs(N, seed=1)
+    xys, _, radii, conics, _ = oracle.project_cholesky_fwd(means.numpy(), L.numpy(), H, W)
+    offs, ids = oracle.bin_tiles(xys, radii, H, W)
+    ref = oracle.rasterize_sum_fwd(xys, conics, col.numpy(), op.numpy(), H, W, offs, ids)
+    d = np.clip(ref, 0, 1) - gt[0].permute(1, 2, 0).cpu().numpy()
+    want_loss = float((d.astype(np.float64) ** 2).mean())
+    # reference-style training on the same parameters through the drop-in operators
+    torch.manual_seed(0)
+    model = harness.CholeskyImageModel(N, H, W, DEV, passes=1)
+    with torch.no_grad():
+        for k, v in params.items():
+            getattr(model, k).copy_(v)
+    K, K_model = 300, 25
+    for it in range(K):
+        fused.step(gt)
+        plain.step(gt)
+        if it == 0:
+            assert abs(fused.loss() - want_loss) <= 1e-6
+        if it < K_model:
+            loss, _ = model.train_iter(gt)
+            assert abs(fused.loss() - loss.item()) <= 2e-6 * max(1.0, loss.item()), it
+        if it == K_model - 1:
+            # Two fp32 implementations of the same trajectory.  Adan divides by sqrt(n) + 1e-8:
+            # an element whose gradient is rounding noise moves by about lr per step in a
+            # direction the last bits decide, so a few elements in 50 000 x 8 may differ by a
+            # multiple of lr; all others agree to a few 1e-5 of the parameter range.
+            for k in params:
+                a, b = fused.params[k].double(), getattr(model, k).detach().double()
+                diff = (a - b).abs() / b.abs().max()
+                assert float((diff <= 2e-4).double().mean()) >= 0.9995, k
+                assert float(diff.max()) <= 2 * K_model * 1e-3, k
+        if it % 50 == 49:
+            assert fused.loss() == plain.loss(), it
+    assert fused.overflowed_frames == 0 and plain.overflowed_frames == 0
+    for k in fused.params:
+        assert torch.equal(fused.params[k], plain.params[k]), k
+        for s in fused.state[k]:
+            assert torch.equal(fused.state[k][s], plain.state[k][s]), (k, s)
+    assert fused.loss() < 0.8 * want_loss  # and it is a fit: the loss goes down
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config5_tile_row_bands_at_full_size(world):
+    from gaussianimage_amd.pipeline import FramePipeline
+    from gaussianimage_amd.sharding import band_pixels, band_plan
+    H, W, N = 2160, 3840, 200000
+    means, L, col, op = synth.cholesky_inputs(N, seed=1)
+    args = [means.to(DEV), L.to(DEV), None, col.to(DEV), op.reshape(-1).to(DEV)]
+    full = FramePipeline(N, H, W, device=DEV)
+    img = full.forward(*args).clone()
+    v_img = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+    ref_grads = [g.clone() for g in full.backward(*args, v_img) if g is not None]
+    del full
+    plan = band_plan((H + 15) // 16, world)
+    assert sum(e - b for b, e in plan) == (H + 15) // 16
+    sums = None
+    for rank in range(world):
+        pipe = FramePipeline(N, H, W, device=DEV, rows=plan[rank])
+        y0, y1 = band_pixels(plan, rank, H)
+        band = pipe.forward(*args)
+        assert band.shape == (y1 - y0, W, 3)
+        assert torch.equal(band, img[y0:y1]), (world, rank)
+        grads = [g.clone() for g in pipe.backward(*args, v_img[y0:y1]) if g is not None]
+        sums = grads if sums is None else [s + g for s, g in zip(sums, grads)]
+        del pipe
+    for s, r, name in zip(sums, ref_grads, ("means", "L", "colors", "opacity")):
+        # the same per-tile partial sums added band by band instead of in one pass
+        _assert_grad(_np(s), _np(r), name, rtol=1e-5, floor=1e-6)

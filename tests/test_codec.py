@@ -52,7 +52,7 @@ def test_oracle_follows_the_reference_expressions(kind):
 
 @pytest.mark.parametrize("kind", KINDS)
 def test_synthetic_codes_have_the_reference_ranges_and_round_trip(kind):
-    from gaussianimage_amd import synth
+    from gaussianimage_amd._testing import synth
     N = 3000
     enc, q = codec_mod.synthetic_encoding(N, kind, seed=5)
     key = "quant_cholesky_elements" if kind == "cholesky" else "quant_scaling"

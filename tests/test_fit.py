@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from gaussianimage_amd import synth
+from gaussianimage_amd._testing import synth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -18,7 +18,7 @@ def _maxrel(a, b):
 
 @pytest.mark.parametrize("kind", ["cholesky", "rs"])
 def test_fused_step_matches_drop_in_training(kind):
-    from gaussianimage_amd import harness
+    from gaussianimage_amd._testing import harness
     from gaussianimage_amd.fit import FusedFitter
     H, W, N, K = 96, 128, 1500, 6
     torch.manual_seed(3)
@@ -87,7 +87,7 @@ def test_growing_gaussians_do_not_stop_a_fit():
     """Footprints that suddenly outgrow the tile lists' capacity (sized from earlier iterations)
     cost the overflowed tiles one step's gradient, never a NaN or an exception: the workspace
     grows and the fit goes on."""
-    from gaussianimage_amd import synth
+    from gaussianimage_amd._testing import synth
     from gaussianimage_amd.fit import FusedFitter
     H, W, N = 64, 80, 3000
     torch.manual_seed(2)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from gaussianimage_amd import synth
+from gaussianimage_amd._testing import synth
 from oracle import torch_oracle as to
 
 SIZES = [(48, 64), (80, 96), (33, 50)]
@@ -185,3 +185,24 @@ def test_conventions_are_runtime(oracle):
         outs.append(oracle.rasterize_sum_fwd(xys, con, col.numpy(), op.numpy(), H, W, offs, ids,
                                              conv=c))
     assert np.abs(outs[0] - outs[1]).max() < 1e-5
+
+
+def test_shared_sincos_against_libm(oracle):
+    """The fixed-sequence sine / cosine that the kernels and the C restatement share: within
+    1.5e-7 of the double-precision functions for |theta| <= 1e5 (dense near [0, 2 pi], the
+    model's range: sigmoid * 2 pi, gaussianimage_rs.py:59-60), NaN outside +-1e9 and for
+    non-finite angles, and exact at zero."""
+    rng = np.random.default_rng(0)
+    theta = np.concatenate([np.linspace(-7, 7, 400001), rng.uniform(-1e5, 1e5, 400000),
+                            rng.uniform(-300, 300, 200000)]).astype(np.float32)
+    s, c = oracle.sincos_f32(theta)
+    t64 = theta.astype(np.float64)
+    assert np.abs(s - np.sin(t64)).max() <= 1.5e-7
+    assert np.abs(c - np.cos(t64)).max() <= 1.5e-7
+    s, c = oracle.sincos_f32(np.array([0.0, 2e9, -2e9, np.inf, -np.inf, np.nan], np.float32))
+    assert s[0] == 0.0 and c[0] == 1.0
+    assert np.isnan(s[1:]).all() and np.isnan(c[1:]).all()
+    # accuracy degrades gracefully up to the 1e9 limit (double-precision reduction)
+    big = rng.uniform(-1e9, 1e9, 100000).astype(np.float32)
+    s, c = oracle.sincos_f32(big)
+    assert np.abs(s - np.sin(big.astype(np.float64))).max() <= 1e-6

@@ -11,7 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gaussianimage_amd import sharding, synth
+from gaussianimage_amd import sharding
+from gaussianimage_amd._testing import synth
 from gaussianimage_amd.sharding import band_pixels, band_plan
 
 

@@ -10,7 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from gaussianimage_amd import synth  # noqa: E402
+from gaussianimage_amd._testing import synth  # noqa: E402
 from gaussianimage_amd.fit import FusedFitter  # noqa: E402
 
 ap = argparse.ArgumentParser()

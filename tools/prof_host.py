@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from gaussianimage_amd import harness, synth  # noqa: E402
+from gaussianimage_amd._testing import harness, synth  # noqa: E402
 
 dev = "cuda:0"
 torch.manual_seed(1)

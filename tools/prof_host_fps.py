@@ -8,7 +8,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from gaussianimage_amd import harness  # noqa: E402
+from gaussianimage_amd._testing import harness  # noqa: E402
 
 dev = "cuda:0"
 torch.manual_seed(1)
