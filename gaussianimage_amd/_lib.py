@@ -32,6 +32,8 @@ OPT_BWD_SERIAL = 4
 BLOCK = 16
 MAX_COLOR_SETS = 3  # GI2D_MAX_COLOR_SETS
 MAX_VQ_LAYERS = 8   # GI2D_MAX_VQ_LAYERS
+NOALLOC_MAX_TILES = 34816        # GI2D_NOALLOC_MAX_TILES
+NOALLOC_MAX_LIST_INTS = 2097152  # GI2D_NOALLOC_MAX_LIST_INTS
 
 
 class AdanHyper(ctypes.Structure):
@@ -98,6 +100,7 @@ SIGNATURES = {
     "gi2d_render_rs_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_render_frame": (_i, [ctypes.POINTER(FrameArgs)]),
+    "gi2d_render_frame_noalloc": (_i, [ctypes.POINTER(FrameArgs), _i]),
     "gi2d_fit_backward_step_chain": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp,
                                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           ctypes.POINTER(AdanHyper), _vp]),

@@ -10,7 +10,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["lists.hip", "project.hip", "raster_fwd.hip", "raster_bwd.hip", "fit.hip"]
+SOURCES = ["lists.hip", "project.hip", "raster_fwd.hip", "raster_bwd.hip", "fit.hip",
+           "noalloc.hip"]
 LIB = os.path.join(CSRC, "libgi2d.so")
 OBJ_DIR = os.path.join(CSRC, "_build")
 

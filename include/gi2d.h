@@ -204,6 +204,24 @@ typedef struct gi2d_frame_args {
 } gi2d_frame_args;
 int gi2d_render_frame(const gi2d_frame_args *args);
 
+/* gi2d_render_frame for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
+ * reference.  args->ws must be NULL: the tile lists live in a file-scope device array of the
+ * library (about 12.4 MiB, one copy per GPU the call is used on, held until the process ends)
+ * on the CURRENT device, and the call itself -- after its first use on a device, which looks up
+ * the array's address -- calls no hipMalloc / hipFree and nothing else that allocates.
+ * Limits: at most GI2D_NOALLOC_MAX_TILES tiles (a 3840x2160 frame has 32 400) and
+ * tiles * capacity <= GI2D_NOALLOC_MAX_LIST_INTS ids; beyond them GI2D_E_CAPACITY.
+ * per_tile_capacity: ids reserved per tile (rounded up to a multiple of 64); 0 = as many as the
+ * array gives this frame, at most 4096.  There is no growth: a tile whose list is longer has
+ * its pixels set to NaN (never silently wrong), as in the asynchronous workspace path.
+ * Results are bit-identical to gi2d_render_frame's.  Every call on a GPU shares that GPU's
+ * array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream
+ * are ordered and each clears what it needs cleared. */
+#define GI2D_NOALLOC_MAX_TILES 34816
+#define GI2D_NOALLOC_MAX_LIST_INTS 2097152
+int gi2d_render_frame_noalloc(const gi2d_frame_args *args, int per_tile_capacity);
+
 /* Adan optimizer step for the parameter tensors of the fitted image, the step
  * that follows the path in every training iteration
  * (gaussianimage_cholesky.py:120 -> optimizer.py:125-235, update rule
