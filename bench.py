@@ -2,21 +2,30 @@
 """Benchmark of the hot path: project -> tile binning -> rasterize_sum (forward), through the
 C ABI, on synthetic parameters with the reference models' own initial distributions.
 
-    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--batch B]
 
-One "step" is one forward pass of the hot path over one frame whose operator inputs are
-already resident in HBM.  N=1 runs BASELINE config 2 (768x512, 30k Gaussians, Cholesky).
+One "step" is one pass of the hot path over one BATCH of B independent frames (default 8, each
+with its own Gaussians) whose operator inputs are already resident in HBM: one C call
+(gi2d_render_batch), two launches.  N=1 runs BASELINE config 2 (768x512, 30k Gaussians,
+Cholesky).  `value` is frames per second.  The timed region is EXACTLY K steps between
+synchronisations; because K steps of this path last only about a millisecond, that region is
+repeated until at least `--min-time-ms` have been timed and the median region is reported
+(`timed_regions`, `frames_timed` say how much that was).
 For N>1 (launched under torch.distributed.run, one rank per GPU) every rank renders its own
-frames of that configuration -- frames are independent units, so there is no data-path
-collective and scaling is weak -- and, as a secondary measurement reported under
-``tile_row_sharded``, the ranks render ONE 3840x2160 / 200k frame split by tile rows with an
-RCCL all-gather of the bands.
+batches -- frames are independent units, so there is no data-path collective and scaling is weak
+-- and, as a secondary measurement reported under ``tile_row_sharded``, the ranks render ONE
+3840x2160 / 200k frame split by tile rows.
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
-  roofline      -- the dominant kernel (rasterize_sum forward) against the HBM roofline,
+  roofline      -- the dominant kernel (rasterize_sum forward) against the HBM roofline, its
+                   launch time taken from HIP events the library records around the launch on
+                   the launch stream, inside the timed regions,
+  kernels       -- the same for every kernel of the forward, backward and fused fitting step,
+  train_step    -- the other half of the metric: ms per training iteration (reference-style
+                   loop, fused step, forward+backward alone),
   cpu_baseline  -- this repository's CPU oracle timed on the host cores (a reported
                    baseline; the reference has no CPU path),
-  extras        -- forward+backward ms, per-stage times, the reference-style FPS loop.
+  extras        -- single-frame latency-bound rates, stages, decode, concurrency.
 """
 import argparse
 import json
@@ -40,6 +49,11 @@ WORKLOADS = {
     "kodak30k_fitted": (512, 768, 30000, "cholesky", 3.0),  # larger footprints (fitted-like)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+VALU_PEAK_INSTR_S = 256 * 4 * 2.4e9 / 4  # wave64 instructions/s: 256 CUs x 4 SIMDs, 4 cycles each
+
+
+def tiles_of(H, W):
+    return ((W + 15) // 16) * ((H + 15) // 16)
 
 
 def make_inputs(name, device, seed=1):
@@ -54,11 +68,45 @@ def make_inputs(name, device, seed=1):
     return tuple(None if a is None else a.to(device).contiguous() for a in args)
 
 
+def make_batch_inputs(name, device, frames, seed=1):
+    """`frames` different frames of the workload as contiguous [frames, N, ...] tensors."""
+    per = [make_inputs(name, device, seed=seed + f) for f in range(frames)]
+    return tuple(None if per[0][k] is None else torch.stack([p[k] for p in per]).contiguous()
+                 for k in range(5))
+
+
+def bound_batch(name, device, frames, seed=1):
+    """(FrameBatch, run()) for `frames` different frames of a workload."""
+    from gaussianimage_amd.pipeline import FrameBatch
+    H, W, N, kind, _ = WORKLOADS[name]
+    fb = FrameBatch(frames, N, H, W, kind=kind, device=device)
+    return fb, fb.bind(*make_batch_inputs(name, device, frames, seed=seed))
+
+
+# ---- algorithmic bytes (minimal traffic of an ideal implementation, fp32, 3 channels) ----------
 def algorithmic_bytes_raster(I, P, T):
-    """Minimal traffic of one rasterize_sum forward launch: per intersection the Gaussian id
-    (4 B) and its gathered xy (8), conic (12), opacity (4), colour (12); per pixel the 12 B
-    written; per tile its two list bounds."""
+    """rasterize_sum forward: per intersection the Gaussian id (4 B) and its gathered xy (8),
+    conic (12), opacity (4), colour (12); per pixel the 12 B written; per tile its list bounds."""
     return 40 * I + 12 * P + 8 * T
+
+
+def algorithmic_bytes(kernel, N, I, P, T):
+    """Per launch, for N Gaussians, I (tile, Gaussian) intersections, P pixels, T tiles."""
+    return {
+        # read means + covariance parameters, write the five outputs, one id + one counter word
+        # per intersection
+        "project": 20 * N + 32 * N + 8 * I,
+        "raster_fwd": algorithmic_bytes_raster(I, P, T),
+        # read v_out, re-gather the attributes, write nine partial sums + their stamp
+        "raster_bwd": 12 * P + 40 * I + 40 * I,
+        # read the partial sums, xys and radii; write v_xy, v_conic, v_colors, v_opacity
+        "gather": 40 * I + 12 * N + 36 * N,
+        # forward + loss + backward pass 1 in one kernel: target image in, partial sums out
+        "fit_raster": 12 * P + 40 * I + 40 * I + 4 * T,
+        # partial sums in; 8 parameters x (p, m, n, d, prev) read and written; the next frame's
+        # projection outputs and list entries out
+        "fit_tail": 40 * I + 8 * 4 * 5 * 2 * N + 32 * N + 8 * I,
+    }[kernel]
 
 
 def time_cpu_oracle(name, budget_s=12.0):
@@ -128,38 +176,85 @@ class no_gc:
             gc.enable()
 
 
-def bench_forward(pipe, inputs, steps, warmup, sync_all):
-    """K forward frames, one C call each (gi2d_render_*_fwd).  The rasterize launch of every
-    timed frame is bracketed by HIP events recorded inside that call on the launch stream."""
-    means, cov_a, cov_b, col, op = inputs
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(steps)]
-    for a, b in ev:  # give every event its handle outside the timed region
-        a.record()
-        b.record()
-    run = pipe.bind(means, cov_a, cov_b, col, op)
+class Probe:
+    """HIP-event brackets around one kind of kernel launch, recorded by the library itself on the
+    launch stream (gi2d_workspace_set_probe): `arm()` before a call that contains the launch,
+    `disarm()` after it; `ms()` reads the durations once everything has completed."""
+
+    def __init__(self, ws, kernel, pairs):
+        from gaussianimage_amd import _lib
+        self._lib, self.ws, self.kernel = _lib, ws, _lib.PROBE[kernel]
+        self.pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                      for _ in range(pairs)]
+        for a, b in self.pairs:   # a torch event gets its handle when first recorded
+            a.record()
+            b.record()
+        self.used = 0
+
+    def arm(self):
+        a, b = self.pairs[self.used]
+        self.used += 1
+        self._lib.lib.gi2d_workspace_set_probe(self.ws.handle, self.kernel, a.cuda_event,
+                                               b.cuda_event)
+
+    def disarm(self):
+        self._lib.lib.gi2d_workspace_set_probe(self.ws.handle, 0, None, None)
+
+    def ms(self):
+        return sorted(a.elapsed_time(b) for a, b in self.pairs[:self.used])
+
+
+def probe_kernel(ws, kernel, fn, reps=48, warmup=4):
+    """Average launch duration (ms) of `kernel` over `reps` calls of fn() -- outside the headline's
+    timed regions; every call is bracketed."""
+    for _ in range(warmup):
+        fn()
+    p = Probe(ws, kernel, reps)
+    for _ in range(reps):
+        p.arm()
+        fn()
+    p.disarm()
+    torch.cuda.synchronize()
+    ms = p.ms()
+    return {"avg_launch_ms": sum(ms) / len(ms), "median_launch_ms": ms[len(ms) // 2],
+            "launches": len(ms)}
+
+
+def roofline_entry(kernel, timing, N, I_8d, I_held, P, T):
+    """HBM-roofline entry of one kernel: algorithmic bytes with the intersections as the
+    reference counts them (sum of num_tiles_hit), and with the list entries actually held."""
+    b8d = algorithmic_bytes(kernel, N, I_8d, P, T)
+    bheld = algorithmic_bytes(kernel, N, I_held, P, T)
+    t = timing["avg_launch_ms"] * 1e-3
+    return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": b8d, "achieved": b8d / t / 1e9,
+            "frac": b8d / t / 1e9 / HBM_PEAK_GBS,
+            "bytes_with_lists_held": bheld, "achieved_lists_held": bheld / t / 1e9,
+            "frac_lists_held": bheld / t / 1e9 / HBM_PEAK_GBS, **timing}
+
+
+def bench_regions(run, steps, warmup, sync_all, min_time_s, probe=None, probe_every=4):
+    """Times regions of EXACTLY `steps` calls of run(), each between synchronisations, until
+    `min_time_s` seconds have been timed (at least 3 regions, at most 400).  Returns the list of
+    region times.  `probe`: bracket every `probe_every`-th step's dominant launch."""
     for _ in range(warmup):
         run()
+    regions = []
     with no_gc():
-        sync_all()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            # every 8th frame is bracketed: an event pair costs the GPU ~2 us of its own
-            run(ev[k] if k % 8 == 0 else None)
-        sync_all()
-        el = time.perf_counter() - t0
-    raster_ms = sorted(a.elapsed_time(b) for a, b in ev[::8])
-    # What an event pair measures with NOTHING between the two records, on the same busy
-    # stream (outside the timed region): the bracket's own share of a bracketed launch.
-    empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-             for _ in range(48)]
-    for a, b in empty:
-        run()
-        a.record()
-        b.record()
-    sync_all()
-    empty_ms = sorted(a.elapsed_time(b) for a, b in empty)
-    return el, raster_ms, empty_ms[len(empty_ms) // 2]
+        while True:
+            sync_all()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                if probe is not None and k % probe_every == 0 and probe.used < len(probe.pairs):
+                    probe.arm()
+                    run()
+                    probe.disarm()
+                else:
+                    run()
+            sync_all()
+            regions.append(time.perf_counter() - t0)
+            if len(regions) >= 400 or (len(regions) >= 3 and sum(regions) >= min_time_s):
+                return regions
 
 
 def bench_region(fn, steps, warmup):
@@ -175,11 +270,11 @@ def bench_region(fn, steps, warmup):
 
 
 def bench_model_loops(name, device, steps):
-    """The reference's own two loops on a stand-in of its model (gaussianimage_amd/_testing/harness.py),
-    through the drop-in operators: train_iter (forward, L2 loss, backward, PSNR .item(), Adan
-    step, StepLR -- /root/reference/train.py:141-145) and the FPS loop (100 x model() under
-    eval + no_grad, wall clock -- /root/reference/train.py:242-249; synchronised at both ends
-    here)."""
+    """The reference's own two loops on a stand-in of its model
+    (gaussianimage_amd/_testing/harness.py), through the drop-in operators: train_iter (forward,
+    L2 loss, backward, PSNR .item(), Adan step, StepLR -- /root/reference/train.py:141-145) and
+    the FPS loop (100 x model() under eval + no_grad, wall clock --
+    /root/reference/train.py:242-249; synchronised at both ends here)."""
     from gaussianimage_amd._testing import harness, synth
     H, W, N, kind, _ = WORKLOADS[name]
     torch.manual_seed(1)
@@ -287,10 +382,10 @@ def bench_decode(name, device, steps):
 
 def bench_concurrent(name, inputs, device, steps, streams=4):
     """Throughput with several independent frames in flight: `streams` pipelines, each with its
-    own workspace and HIP stream (default priority), frames issued round-robin.  A single
-    frame's kernels are latency-bound and leave most of the chip idle; independent frames
-    (a batch of images, video frames) overlap.  The headline `value` stays the one-stream rate."""
-    from gaussianimage_amd.pipeline import FramePipeline
+    own workspace and HIP stream (default priority), frames issued round-robin; and the packaged
+    ring for one caller.  (The batched call of the headline gets the same overlap by design, in
+    one launch pair, without depending on which hardware queues the streams land on.)"""
+    from gaussianimage_amd.pipeline import FramePipeline, FrameRing
     H, W, N, kind, _ = WORKLOADS[name]
     runs = []
     for _ in range(streams):
@@ -300,8 +395,6 @@ def bench_concurrent(name, inputs, device, steps, streams=4):
             for _ in range(5):
                 run()
         runs.append(run)
-    # (the first few hundred overlapping launches of a process run well below the steady rate:
-    # warm the streams up together, not only one by one)
     for k in range(400):
         runs[k % streams]()
     with no_gc():
@@ -311,8 +404,6 @@ def bench_concurrent(name, inputs, device, steps, streams=4):
             runs[k % streams]()
         torch.cuda.synchronize()
         out = {"fps_%d_streams" % streams: steps / (time.perf_counter() - t0)}
-    # the same for ONE caller through the packaged ring (two frames in flight)
-    from gaussianimage_amd.pipeline import FrameRing
     for depth in (2, 4):
         ring = FrameRing(N, H, W, kind=kind, device=device, depth=depth)
         for _ in range(200):
@@ -328,77 +419,184 @@ def bench_concurrent(name, inputs, device, steps, streams=4):
     return out
 
 
+def make_fitter(name, device, spatial_order=False):
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N, kind, fp = WORKLOADS[name]
+    f = FusedFitter(N, H, W, kind=kind, device=device, keep_image=False,
+                    spatial_order=spatial_order)
+    if fp != 1.0 and kind == "cholesky":
+        bound = torch.tensor([0.5, 0.0, 0.5], device=device)
+        f.params["_cholesky"].copy_((f.params["_cholesky"] + bound) * fp - bound)
+    return f
+
+
 def bench_fused_fit(name, device, steps, concurrent=True):
     """The fused fitting iteration (gaussianimage_amd/fit.py): forward, L2 loss, backward and
     Adan step in two launches on the raw parameters, no host synchronisation inside the loop.
-    The workload's footprint scales the initial Cholesky factors as it does the forward inputs."""
+    The workload's footprint scales the initial Cholesky factors as it does the forward inputs.
+    Returns (figures, fitter, target)."""
     from gaussianimage_amd._testing import synth
-    from gaussianimage_amd.fit import FusedFitter
     H, W, N, kind, fp = WORKLOADS[name]
-
-    def make(spatial_order=False):
-        f = FusedFitter(N, H, W, kind=kind, device=device, keep_image=False,
-                        spatial_order=spatial_order)
-        if fp != 1.0 and kind == "cholesky":
-            bound = torch.tensor([0.5, 0.0, 0.5], device=device)
-            f.params["_cholesky"].copy_((f.params["_cholesky"] + bound) * fp - bound)
-        return f
-
     torch.manual_seed(1)
-    fit = make()
+    fit = make_fitter(name, device)
     gt = synth.target_image(H, W).to(device)
-    for _ in range(10):
-        fit.step(gt)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fit.step(gt)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    ms = bench_region(lambda: fit.step(gt), steps, 10)
     out = {"fused_train_step_ms": ms, "fused_train_iters_per_s": 1e3 / ms,
            "fused_train_psnr_after_%d_iters" % (steps + 10): fit.psnr()}
-    # the same with the Gaussians kept in tile order (shared list atomics)
     torch.manual_seed(1)
-    fit = make(spatial_order=True)
-    for _ in range(10):
-        fit.step(gt)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fit.step(gt)
-    torch.cuda.synchronize()
-    out["fused_train_step_ms_spatial_order"] = (time.perf_counter() - t0) / steps * 1e3
-    del fit
-    if not concurrent:
-        return out
-    # several images fitted at once (the reference fits the images of a dataset one after the
-    # other, /root/reference/train.py:306-316): one fitter per HIP stream, default priority
-    streams = 4
-    fits = []
-    for _ in range(streams):
-        st = torch.cuda.Stream(device=device)
-        with torch.cuda.stream(st):
-            fits.append(make())
-    torch.cuda.synchronize()
-    for _ in range(5):
-        for f in fits:
-            f.step(gt)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        for f in fits:
-            f.step(gt)
-    torch.cuda.synchronize()
-    out["fused_train_iters_per_s_%d_streams" % streams] = streams * steps / (time.perf_counter() - t0)
+    fit_s = make_fitter(name, device, spatial_order=True)
+    out["fused_train_step_ms_spatial_order"] = bench_region(lambda: fit_s.step(gt), steps, 10)
+    del fit_s
+    if concurrent:
+        # several images fitted at once (the reference fits the images of a dataset one after
+        # the other, /root/reference/train.py:306-316): one fitter per HIP stream
+        streams = 4
+        fits = []
+        for _ in range(streams):
+            st = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(st):
+                fits.append(make_fitter(name, device))
+        torch.cuda.synchronize()
+        ms4 = bench_region(lambda: [f.step(gt) for f in fits], steps, 5)
+        out["fused_train_iters_per_s_%d_streams" % streams] = streams * 1e3 / ms4
+    return out, fit, gt
+
+
+def secondary(args, device, batch, run, batch_in, B, I_8d, I_held, raster_batch_ms):
+    """Per-kernel roofline entries, the training-step half of the metric, and the extras."""
+    from gaussianimage_amd.pipeline import FramePipeline
+    H, W, N, kind, fp = WORKLOADS[args.workload]
+    P, T = H * W, tiles_of(H, W)
+    k = max(20, args.steps // 2)
+    out, ex, kernels = {}, {}, {}
+
+    # ---- single frame (the latency-bound rate: two launches per frame, one frame in flight) ----
+    inputs = tuple(None if t is None else t[0].contiguous() for t in batch_in)
+    means, cov_a, cov_b, col, op = inputs
+    pipe = FramePipeline(N, H, W, kind=kind, device=device)
+    if args.raster_ppl:
+        pipe.ws.set_raster_ppl(args.raster_ppl)
+    run1 = pipe.bind(*inputs)
+    ex["single_frame_fps"] = 1e3 / bench_region(run1, max(args.steps, 200), 20)
+    I1_8d = int(pipe.num_tiles_hit.sum().item())
+    I1_held = pipe.intersections()
+    run1()
+    v_img = torch.randn(H, W, 3, device=device)
+
+    def bwd():
+        pipe.backward(means, cov_a, cov_b, col, op, v_img)
+
+    def fwd_bwd():
+        run1()
+        bwd()
+
+    # ---- per-kernel launch times (library-recorded HIP events) and roofline fractions ----------
+    kernels["project (batch of %d)" % B] = roofline_entry(
+        "project", probe_kernel(batch.ws, "project", run), B * N, I_8d, I_held, B * P, B * T)
+    kernels["project (1 frame)"] = roofline_entry(
+        "project", probe_kernel(pipe.ws, "project", run1), N, I1_8d, I1_held, P, T)
+    kernels["raster_fwd (1 frame)"] = roofline_entry(
+        "raster_fwd", probe_kernel(pipe.ws, "raster_fwd", run1), N, I1_8d, I1_held, P, T)
+    kernels["raster_bwd (1 frame)"] = roofline_entry(
+        "raster_bwd", probe_kernel(pipe.ws, "raster_bwd", fwd_bwd), N, I1_8d, I1_held, P, T)
+    kernels["gather (1 frame)"] = roofline_entry(
+        "gather", probe_kernel(pipe.ws, "gather", fwd_bwd), N, I1_8d, I1_held, P, T)
+
+    # ---- the training step: the other half of the metric ----------------------------------------
+    fwd_bwd_ms = bench_region(fwd_bwd, k, 5)
+    fit_figs, fit, gt = bench_fused_fit(args.workload, device, max(k, 100),
+                                        concurrent=not args.no_concurrent)
+    fit.forward(gt)   # (a plain forward: the lists of the current parameters, finalised)
+    I_fit = int(fit.ws.offsets()[-1].item())
+    I_fit_8d = int(fit.num_tiles_hit.sum().item())
+    kernels["fit_raster (1 frame)"] = roofline_entry(
+        "fit_raster", probe_kernel(fit.ws, "fit_raster", lambda: fit.step(gt)), N, I_fit_8d,
+        I_fit, P, T)
+    kernels["fit_tail (1 frame)"] = roofline_entry(
+        "fit_tail", probe_kernel(fit.ws, "fit_tail", lambda: fit.step(gt)), N, I_fit_8d, I_fit,
+        P, T)
+    model_figs = bench_model_loops(args.workload, device, k)
+    # bytes per iteration: forward (projection + lists + gathers + image), backward (v_out,
+    # re-gather, partial sums, per-Gaussian gradients, projection backward), and the Adan
+    # step's single-pass traffic over the 8 N parameter floats
+    b_fwd = 20 * N + 32 * N + 4 * I1_8d + 8 * T + 40 * I1_8d + 12 * P
+    b_bwd = 12 * P + 40 * I1_8d + 36 * I1_8d + 36 * N + 40 * N
+    b_adan = 8 * N * 4 * 11
+    fused_ms = fit_figs["fused_train_step_ms"]
+    out["train_step"] = {
+        "unit": "ms per iteration (forward + L2 loss + backward + Adan), 1 frame",
+        "fused_ms": fused_ms, "fused_iters_per_s": 1e3 / fused_ms,
+        "reference_style_ms": model_figs["train_step_ms"],
+        "reference_style_note": model_figs["train_step_note"],
+        "fwd_bwd_ms": fwd_bwd_ms,
+        "algorithmic_bytes": {"forward": b_fwd, "backward": b_bwd, "adan": b_adan},
+        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                     "achieved": (b_fwd + b_bwd + b_adan) / (fused_ms * 1e-3) / 1e9,
+                     "frac": (b_fwd + b_bwd + b_adan) / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "what": "the whole fused step (2 launches): forward + backward + Adan "
+                             "bytes / step time"},
+        "fwd_bwd_roofline_frac": (b_fwd + b_bwd) / (fwd_bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }
+    out["kernels"] = kernels
+
+    # ---- extras -------------------------------------------------------------------------------
+    ex.update({k_: v for k_, v in fit_figs.items() if k_ != "fused_train_step_ms"})
+    ex.update({k_: v for k_, v in model_figs.items() if k_ not in ("train_step_ms",
+                                                                   "train_step_note")})
+    ex["bwd_only_ms"] = bench_region(bwd, k, 5)
+    three = [col, torch.rand_like(col) * 0.5, torch.ones_like(col)]
+    pipe.project(means, cov_a, cov_b)
+    pipe.bin()
+    ex["rasterize_ms"] = bench_region(lambda: pipe.rasterize(col, op), k, 5)
+    ex["rasterize_3sets_one_launch_ms"] = bench_region(lambda: pipe.rasterize_multi(three, op), k, 5)
+    ex["rasterize_3sets_three_launches_ms"] = bench_region(
+        lambda: [pipe.rasterize(c, op) for c in three], k, 5)
+    # Pair evaluations per second (256 lanes per listed intersection): the inner loop is VALU
+    # and transcendental work on cache-resident data, not HBM traffic.
+    ex["pair_evals_per_s_batched"] = I_held * 256 / (raster_batch_ms * 1e-3)
+    if not args.no_concurrent:
+        ex.update(bench_concurrent(args.workload, inputs, device, max(args.steps, 200)))
+        sweep = {}
+        for b in (1, 2, 4, 16):   # the headline call at other batch sizes
+            fb, frun = bound_batch(args.workload, device, b)
+            sweep[str(b)] = b * 1e3 / bench_region(frun, 60, 10)
+            del fb, frun
+        ex["fps_by_batch_size"] = sweep
+    if args.workload == "kodak30k" and not args.no_concurrent:
+        # the one-GPU point of the tile-row scaling series (3840x2160 / 200k Gaussians)
+        uh, uw, un, ukind, _ = WORKLOADS["uhd200k"]
+        big = FramePipeline(un, uh, uw, kind=ukind, device=device)
+        big_in = make_inputs("uhd200k", device, seed=1)
+        big_v = torch.randn(uh, uw, 3, device=device)
+        brun = big.bind(*big_in)
+        ex["uhd200k_1gpu_forward_ms"] = bench_region(brun, 50, 5)
+        ex["uhd200k_1gpu_fwd_bwd_ms"] = bench_region(
+            lambda: (brun(), big.backward(*big_in, big_v)), 50, 5)
+        Ib = int(big.num_tiles_hit.sum().item())
+        Ibh = big.intersections()
+        brun()
+        kernels["raster_fwd (uhd200k, 1 frame)"] = roofline_entry(
+            "raster_fwd", probe_kernel(big.ws, "raster_fwd", brun), un, Ib, Ibh, uh * uw,
+            tiles_of(uh, uw))
+        kernels["project (uhd200k, 1 frame)"] = roofline_entry(
+            "project", probe_kernel(big.ws, "project", brun), un, Ib, Ibh, uh * uw,
+            tiles_of(uh, uw))
+        del big, big_in, big_v
+    ex.update(bench_decode(args.workload, device, k))
+    out["extras"] = ex
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="kodak30k", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per step (0 = 8, or 1 for frames of 20 000 tiles and more)")
+    ap.add_argument("--min-time-ms", type=float, default=60.0,
+                    help="keep timing K-step regions until this much has been timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0,
                     help="seconds of host work spent on the CPU baseline sample")
@@ -437,57 +635,65 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    from gaussianimage_amd.pipeline import FramePipeline
+    from gaussianimage_amd.pipeline import FrameBatch
 
     # every measurement below runs with the cyclic garbage collector off (see no_gc); the
     # process is short-lived
     no_gc().__enter__()
     H, W, N, kind, fp = WORKLOADS[args.workload]
-    inputs = make_inputs(args.workload, device, seed=1 + rank)
-    pipe = FramePipeline(N, H, W, kind=kind, device=device)
+    P, T = H * W, tiles_of(H, W)
+    B = args.batch or (8 if T < 20000 else 1)
+    batch_in = make_batch_inputs(args.workload, device, B, seed=1 + rank * B)
+    batch = FrameBatch(B, N, H, W, kind=kind, device=device)
     if args.raster_ppl:
-        pipe.ws.set_raster_ppl(args.raster_ppl)
-    pipe.forward(*inputs)
+        batch.ws.set_raster_ppl(args.raster_ppl)
+    run = batch.bind(*batch_in)
+    run()
+    run()
     # intersections as the reference counts them: the sum of num_tiles_hit (every tile of the
-    # radius box), whatever part of them the lists actually hold after culling
-    I = int(pipe.num_tiles_hit.sum().item())
-    P, T = H * W, pipe.tiles_x * pipe.tiles_y
+    # radius box) -- and the (tile, Gaussian) pairs the lists actually hold after culling
+    I_8d = int(batch.num_tiles_hit.sum().item())
+    I_held = batch.intersections()
+    run()
 
-    el, raster_ms, empty_bracket_ms = bench_forward(pipe, inputs, args.steps, args.warmup,
-                                                    sync_all)
+    probe = Probe(batch.ws, "raster_fwd", 256)
+    regions = bench_regions(run, args.steps, args.warmup, sync_all, args.min_time_ms * 1e-3,
+                            probe=probe)
+    el = sorted(regions)[len(regions) // 2]
     if distributed:
         t = torch.tensor([el], dtype=torch.float64,
                          device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     ms_per_step = el / args.steps * 1e3
-    fps = world * args.steps / el
+    fps = world * B * args.steps / el
 
-    raster_avg_ms = sum(raster_ms) / len(raster_ms)
-    bytes_raster = algorithmic_bytes_raster(I, P, T)
-    achieved = bytes_raster / (raster_avg_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    raster_ms = probe.ms()
+    timing = {"avg_launch_ms": sum(raster_ms) / len(raster_ms),
+              "median_launch_ms": raster_ms[len(raster_ms) // 2],
+              "p10_launch_ms": raster_ms[len(raster_ms) // 10],
+              "p90_launch_ms": raster_ms[(9 * len(raster_ms)) // 10], "launches": len(raster_ms)}
+    # (I_8d and I_held are totals over the batch: the launch covers B*N Gaussians, B*T tiles)
+    roofline = roofline_entry("raster_fwd", timing, B * N, I_8d, I_held, B * P, B * T)
+    roofline["kernel"] = "rasterize_sum_fwd_kernel (one launch renders the step's %d frames)" % B
+    # HBM traffic and instruction counts of the same launch come from counters-only rocprofv3
+    # passes (a separate run of this command; tools/gpu_counters.sh): kept with their source
+    roofline["traffic"] = None
+    cpath = os.path.join(ROOT, "profiles", "r02_counters.json")
+    if os.path.exists(cpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get("rasterize_sum_fwd_kernel")
+            c = json.load(open(cpath)).get("%s_batch%d" % (args.workload, B), {})
+            roofline["traffic"] = c.get("raster_fwd_hbm_bytes")
+            roofline["traffic_source"] = c.get("source")
+            if c.get("raster_fwd_valu_instr"):
+                roofline["valu_issue"] = {
+                    "instr_per_launch": c["raster_fwd_valu_instr"],
+                    "peak_instr_per_s": VALU_PEAK_INSTR_S, "source": c.get("source"),
+                    "frac": c["raster_fwd_valu_instr"] / VALU_PEAK_INSTR_S /
+                    (timing["avg_launch_ms"] * 1e-3)}
         except Exception:
-            traffic = None
-    # wave-level VALU instructions of the rasteriser launch (SQ_INSTS_VALU from a counters-only
-    # rocprofv3 pass of this workload, kept under profiles/) against the chip's issue rate:
-    # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
-    valu = None
-    mpath = os.path.join(ROOT, "profiles", "r01_sq_instruction_mix.json")
-    if os.path.exists(mpath):
-        try:
-            mix = json.load(open(mpath)).get(args.workload, {})
-            for name, c in mix.items():
-                if "rasterize_sum_fwd_kernel<true, false, 1" in name:
-                    peak = 256 * 4 * 2.4e9 / 4
-                    valu = {"instr_per_launch": c["SQ_INSTS_VALU"], "peak_instr_per_s": peak,
-                            "frac": c["SQ_INSTS_VALU"] / peak / (raster_avg_ms * 1e-3)}
-        except Exception:
-            valu = None
+            pass
+
     result = {
         "metric": "render FPS (forward: project + tile binning + rasterize_sum), 768x512 @ 30k "
                   "Gaussians" if args.workload == "kodak30k" else f"render FPS, {args.workload}",
@@ -495,84 +701,22 @@ def main():
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {W}x{H}, {N} Gaussians, {kind} covariance, "
-                               f"model-init distribution seed {1 + rank}, footprint x{fp}",
-                   "intersections": I, "tiles": T,
+                               f"model-init distribution, footprint x{fp}; one step = one batch "
+                               f"of {B} different frames (seeds {1 + rank * B}..{rank * B + B}) "
+                               "in one call",
+                   "frames_per_step": B, "intersections_per_frame": I_8d / B,
+                   "list_entries_per_frame": I_held / B, "tiles_per_frame": T,
                    "parallelism": "1 process/GPU, independent frames per rank"},
-        "roofline": {"bound": "hbm", "kernel": "rasterize_sum_fwd_kernel", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": bytes_raster,
-                     "avg_launch_ms": raster_avg_ms,
-                     "median_launch_ms": raster_ms[len(raster_ms) // 2],
-                     "p10_launch_ms": raster_ms[len(raster_ms) // 10],
-                     "p90_launch_ms": raster_ms[(9 * len(raster_ms)) // 10],
-                     "empty_event_bracket_ms": empty_bracket_ms, "valu_issue": valu},
+        "timed_regions": len(regions), "frames_timed": len(regions) * args.steps * B,
+        "region_ms_min_median_max": [min(regions) * 1e3, sorted(regions)[len(regions) // 2] * 1e3,
+                                     max(regions) * 1e3],
+        "roofline": roofline,
     }
 
     # (the secondary figures are single-GPU figures: the one-rank run carries them)
     if not args.no_extras and rank == 0 and world == 1:
-        ex = {}
-        means, cov_a, cov_b, col, op = inputs
-        v_img = torch.randn(H, W, 3, device=device)
-
-        def fwd_bwd():
-            pipe.forward(means, cov_a, cov_b, col, op)
-            pipe.backward(means, cov_a, cov_b, col, op, v_img)
-
-        k = max(20, args.steps // 2)
-        # the headline loop without its event brackets (each bracketed frame costs ~6 us more)
-        run_plain = pipe.bind(means, cov_a, cov_b, col, op)
-        ex["forward_fps_no_event_brackets"] = 1e3 / bench_region(run_plain, max(args.steps, 100), 10)
-        ex["fwd_bwd_ms"] = bench_region(fwd_bwd, k, 5)
-        ex["project_ms"] = bench_region(lambda: pipe.project(means, cov_a, cov_b), k, 5)
-        pipe.project(means, cov_a, cov_b)
-        pipe.bin()
-
-        def proj_bin():
-            pipe.project(means, cov_a, cov_b)
-            pipe.bin()
-
-        ex["project_bin_ms"] = bench_region(proj_bin, k, 5)
-        ex["rasterize_ms"] = bench_region(lambda: pipe.rasterize(col, op), k, 5)
-        three = [col, torch.rand_like(col) * 0.5, torch.ones_like(col)]
-        ex["rasterize_3sets_one_launch_ms"] = bench_region(
-            lambda: pipe.rasterize_multi(three, op), k, 5)
-        ex["rasterize_3sets_three_launches_ms"] = bench_region(
-            lambda: [pipe.rasterize(c, op) for c in three], k, 5)
-        ex["bwd_only_ms"] = bench_region(
-            lambda: pipe.backward(means, cov_a, cov_b, col, op, v_img), k, 5)
-        # The same Gaussians stored in the order of the tiles their centres fall in (what a
-        # fitter or an encoder that keeps a spatial order hands over): the lanes of a wave then
-        # share their list atomics.  The headline keeps the model's own random order.
-        with torch.no_grad():
-            tcol = ((0.5 * W * means[:, 0] + 0.5 * W) / 16).floor().clamp_(0, (W - 1) // 16)
-            trow = ((0.5 * H * means[:, 1] + 0.5 * H) / 16).floor().clamp_(0, (H - 1) // 16)
-            order = torch.argsort(trow * ((W + 15) // 16) + tcol, stable=True)
-            sorted_in = tuple(None if t is None else t[order].contiguous() for t in inputs)
-        pipe_s = FramePipeline(N, H, W, kind=kind, device=device)
-        run_s = pipe_s.bind(*sorted_in)
-        ex["forward_fps_spatial_order"] = 1e3 / bench_region(run_s, max(k, 100), 10)
-        del pipe_s, run_s
-        # Pair evaluations per second against the fp32 vector peak: the inner loop is VALU
-        # and transcendental work on cache-resident data, not HBM traffic.
-        pairs = I * 256
-        ex["pair_evals_per_s"] = pairs / (raster_avg_ms * 1e-3)
-        if not args.no_concurrent:
-            ex.update(bench_concurrent(args.workload, inputs, device, max(args.steps, 200)))
-        ex.update(bench_model_loops(args.workload, device, k))
-        if args.workload == "kodak30k" and not args.no_concurrent:
-            # the one-GPU point of the tile-row scaling series (3840x2160 / 200k Gaussians)
-            big = FramePipeline(*[WORKLOADS["uhd200k"][i] for i in (2, 0, 1)],
-                                kind=WORKLOADS["uhd200k"][3], device=device)
-            big_in = make_inputs("uhd200k", device, seed=1)
-            big_v = torch.randn(WORKLOADS["uhd200k"][0], WORKLOADS["uhd200k"][1], 3, device=device)
-            ex["uhd200k_1gpu_forward_ms"] = bench_region(lambda: big.forward(*big_in), 50, 5)
-            ex["uhd200k_1gpu_fwd_bwd_ms"] = bench_region(
-                lambda: (big.forward(*big_in), big.backward(*big_in, big_v)), 50, 5)
-            del big, big_in, big_v
-        ex.update(bench_decode(args.workload, device, k))
-        ex.update(bench_fused_fit(args.workload, device, max(k, 100),
-                                  concurrent=not args.no_concurrent))
-        result["extras"] = ex
+        result.update(secondary(args, device, batch, run, batch_in, B, I_8d, I_held,
+                                timing["avg_launch_ms"]))
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         result["cpu_baseline"] = time_cpu_oracle(args.workload, budget_s=args.cpu_budget_s)
         result["cpu_baseline"]["gpu_over_cpu"] = fps / result["cpu_baseline"]["value"]
@@ -581,7 +725,7 @@ def main():
         # Secondary measurement: one 4K frame split by tile rows.  It runs in a watched thread:
         # a collective that never completes (or a rank that died) must not cost the headline
         # line, so after GI2D_SHARD_TIMEOUT_S the ranks stop waiting, rank 0 prints what it has,
-        # and every rank leaves without joining the stuck work.
+        # and every rank leaves -- with a NON-ZERO exit status -- without joining the stuck work.
         import threading
         box = {}
 
@@ -589,8 +733,10 @@ def main():
             try:
                 torch.cuda.set_device(local_rank)
                 from gaussianimage_amd.sharding import bench_tile_row_sharded
-                box["result"] = bench_tile_row_sharded(device, rank, world,
-                                                       steps=max(20, args.steps // 4), warmup=5)
+                wl = "uhd200k"
+                box["result"] = bench_tile_row_sharded(
+                    device, rank, world, WORKLOADS[wl][:4], make_inputs(wl, device, seed=1),
+                    steps=max(20, args.steps // 4), warmup=5, label=wl)
                 dist.barrier()
                 box["done"] = True
             except Exception as e:
@@ -608,7 +754,9 @@ def main():
         if box.get("done"):
             dist.destroy_process_group()
             return
-        os._exit(0)  # stuck or failed collective: do not wait for it at interpreter exit
+        # stuck or failed collective: the headline line is out; do not wait for the stuck work
+        # at interpreter exit, and do not report success
+        os._exit(3)
     if rank == 0:
         print(json.dumps(result), flush=True)
 

@@ -28,6 +28,9 @@ OPT_CULL = 1
 OPT_RASTER_PPL = 2
 OPT_DROP_PENDING = 3
 OPT_BWD_SERIAL = 4
+OPT_RECORDS = 5
+PROBE = {"project": 1, "raster_fwd": 2, "raster_bwd": 3, "gather": 4, "fit_raster": 5,
+         "fit_tail": 6}
 
 BLOCK = 16
 MAX_COLOR_SETS = 3  # GI2D_MAX_COLOR_SETS
@@ -76,6 +79,7 @@ _convp = ctypes.POINTER(Conv)
 # name -> (restype, argtypes); every symbol that include/gi2d.h declares
 SIGNATURES = {
     "gi2d_version": (_i, []),
+    "gi2d_build_id": (ctypes.c_char_p, []),
     "gi2d_error_string": (ctypes.c_char_p, [_i]),
     "gi2d_default_conv": (None, [_convp]),
     "gi2d_workspace_create": (_i, [_i, ctypes.POINTER(_vp)]),
@@ -83,6 +87,7 @@ SIGNATURES = {
     "gi2d_workspace_reserve": (_i, [_vp, _i64, _i]),
     "gi2d_workspace_set_option": (_i, [_vp, _i, _i]),
     "gi2d_workspace_set_rows": (_i, [_vp, _i, _i]),
+    "gi2d_workspace_set_probe": (_i, [_vp, _i, _vp, _vp]),
     "gi2d_workspace_info": (_i, [_vp, ctypes.POINTER(_i64)]),
     "gi2d_project_cholesky_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _convp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp]),
@@ -101,6 +106,8 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_render_frame": (_i, [ctypes.POINTER(FrameArgs)]),
     "gi2d_render_frame_noalloc": (_i, [ctypes.POINTER(FrameArgs), _i]),
+    "gi2d_render_batch": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp, _vp,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gi2d_fit_backward_step_chain": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _convp, _vp,
                                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           ctypes.POINTER(AdanHyper), _vp]),
@@ -130,6 +137,16 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # The ctypes structures above mirror include/gi2d.h by hand, and the kernels change with
+    # their sources: a library built from other sources than the ones next to it is refused.
+    from . import build
+    if os.path.exists(os.path.join(build.CSRC, build.SOURCES[0])):
+        have, want = lib.gi2d_build_id().decode(), build.source_id()
+        if have != want and os.environ.get("GI2D_ALLOW_STALE", "0") != "1":
+            raise ImportError(
+                f"{LIB_PATH} was built from other sources (build id {have}, sources {want}): "
+                "rebuild it with `python -m gaussianimage_amd.build` "
+                "(GI2D_ALLOW_STALE=1 loads it anyway)")
     return lib
 
 

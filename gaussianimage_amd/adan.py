@@ -16,37 +16,29 @@ __all__ = ["Adan"]
 
 
 class Adan(Optimizer):
+    """Constructor arguments as the reference's ``Adan`` (optimizer.py:65-74); ``foreach`` and
+    ``fused`` are accepted and ignored -- there is one implementation here, the fused launch."""
+
     def __init__(self, params, lr=1e-3, betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0,
                  max_grad_norm=0.0, no_prox=False, foreach=True, fused=True):
-        if not 0.0 <= max_grad_norm:
-            raise ValueError('Invalid Max grad norm: {}'.format(max_grad_norm))
-        if not 0.0 <= lr:
-            raise ValueError('Invalid learning rate: {}'.format(lr))
-        if not 0.0 <= eps:
-            raise ValueError('Invalid epsilon value: {}'.format(eps))
-        for i in range(3):
-            if not 0.0 <= betas[i] < 1.0:
-                raise ValueError('Invalid beta parameter at index {}: {}'.format(i, betas[i]))
-        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                        max_grad_norm=max_grad_norm, no_prox=no_prox, foreach=foreach,
-                        fused=fused)
-        super().__init__(params, defaults)
-
-    def __setstate__(self, state):
-        super().__setstate__(state)
-        for group in self.param_groups:
-            group.setdefault('no_prox', False)
+        for name, value in (("lr", lr), ("eps", eps), ("max_grad_norm", max_grad_norm)):
+            if not value >= 0.0:
+                raise ValueError(f"Adan: {name} must be >= 0, got {value}")
+        if len(betas) != 3 or not all(0.0 <= b < 1.0 for b in betas):
+            raise ValueError(f"Adan: three betas in [0, 1) expected, got {betas}")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps,
+                                      weight_decay=weight_decay, max_grad_norm=max_grad_norm,
+                                      no_prox=no_prox, foreach=foreach, fused=fused))
 
     @torch.no_grad()
     def restart_opt(self):
+        """Back to step 0 with zeroed moments (optimizer.py:108-122)."""
         for group in self.param_groups:
             group['step'] = 0
-            for p in group['params']:
-                if p.requires_grad:
-                    state = self.state[p]
-                    state['exp_avg'] = torch.zeros_like(p)
-                    state['exp_avg_sq'] = torch.zeros_like(p)
-                    state['exp_avg_diff'] = torch.zeros_like(p)
+        for state in self.state.values():
+            for key in ('exp_avg', 'exp_avg_sq', 'exp_avg_diff'):
+                if key in state:
+                    state[key].zero_()
 
     @torch.no_grad()
     def step(self, closure=None):

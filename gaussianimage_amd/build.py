@@ -3,6 +3,7 @@
 One hipcc compile per translation unit (in parallel), one link.  Objects go to
 ``csrc/_build`` (ignored by git); only the ``.so`` is loaded at run time."""
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -34,6 +35,17 @@ def _deps():
     return deps
 
 
+def source_id():
+    """Hash of every source the library is built from (the .hip / .h files of csrc and the
+    public header): compiled into the library as gi2d_build_id() and compared at load time, so
+    that a library older than its sources cannot be used unnoticed."""
+    h = hashlib.sha256()
+    for d in sorted(_deps()):
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
@@ -47,10 +59,12 @@ def build_native(force=False, extra_flags=(), verbose=False, jobs=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs = []
     cmds = []
+    build_id = '-DGI2D_BUILD_ID="%s"' % source_id()
     for s in SOURCES:
         obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        cmds.append([hipcc(), *HIPCC_FLAGS, *extra_flags, "-c", os.path.join(CSRC, s), "-o", obj])
+        cmds.append([hipcc(), *HIPCC_FLAGS, *extra_flags, build_id, "-c", os.path.join(CSRC, s),
+                     "-o", obj])
 
     def run(cmd):
         if verbose:

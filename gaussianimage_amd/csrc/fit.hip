@@ -18,10 +18,10 @@
 // iteration's tile lists (into the workspace's second list set).
 struct ChainArgs {
     float center_bias;
-    float *depths, *conics;
-    int *num_tiles_hit;
-    int *next_count, *next_seg;
+    ProjOut out;       // the projection outputs to overwrite (xys / radii are also read first)
+    TileLists lists;   // the next frame's lists
     ListCull cull;
+    RecordSink rec;    // the next frame's per-Gaussian records
     const DevStatus *status;
     volatile long long *h_status;
     long long generation;
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
     const float nc0 = adan_apply(h, T, 1, RS ? g2 : g3, c0, o0);
     const float nc1 = adan_apply(h, T, 1, (RS ? g2 : g3) + 1, c1, o1);
     const float nc2 = adan_apply(h, T, RS ? 2 : 1, RS ? (size_t)g : g3 + 2, c2, o2);
-    adan_apply(h, T, 3, g3, f0, acc[5]);
-    adan_apply(h, T, 3, g3 + 1, f1, acc[6]);
-    adan_apply(h, T, 3, g3 + 2, f2, acc[7]);
+    const float nf0 = adan_apply(h, T, 3, g3, f0, acc[5]);
+    const float nf1 = adan_apply(h, T, 3, g3 + 1, f1, acc[6]);
+    const float nf2 = adan_apply(h, T, 3, g3 + 2, f2, acc[7]);
     if (CHAIN) {
         // the next iteration's projection of this Gaussian: the same arithmetic as
         // project_*_fwd_kernel<RAW = true> on the parameters just written
@@ -121,9 +121,8 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
             sxy = c * s * (q1 - q2);
             syy = s * s * q1 + c * c * q2;
         }
-        project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, ch.center_bias, xys,
-                     ch.depths, radii, ch.conics, ch.num_tiles_hit, ch.next_count, ch.next_seg, C,
-                     row0, row1, ch.cull);
+        project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, ch.center_bias, ch.out,
+                     ch.lists, ch.cull, ch.rec, nf0, nf1, nf2);
     }
 }
 
@@ -201,7 +200,7 @@ __device__ __forceinline__ void fit_bwd_64(
 
 // PPL = 1: 256 lanes per tile; PPL = 4: one wave per tile (the forward renders four pixels per
 // lane, the backward gives each entry 4 to 16 lanes and has no work-piece path).
-template <bool FINALIZE, int PPL>
+template <bool FINALIZE, int PPL, bool PACKED>
 // (8 waves per SIMD for the 256-lane form, as in rasterize_sum_bwd_kernel; the one-wave form is
 // limited by its LDS)
 __global__ __launch_bounds__(256 / PPL)
@@ -209,8 +208,9 @@ __attribute__((amdgpu_waves_per_eu(PPL == 1 ? 8 : 5, 8))) void
 fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
                   const int *__restrict__ radii, const float *__restrict__ conics,
                   const float *__restrict__ colors, const float *__restrict__ opacity,
-                  const float *__restrict__ background, int H, int W, int tiles_x, int tiles_y,
-                  int row0, int T, gi2d_conv cv, int cull, DevStatus *status,
+                  const float *__restrict__ rec, const float *__restrict__ background, int H,
+                  int W, int tiles_x, int tiles_y, int row0, int T, gi2d_conv cv, int cull,
+                  DevStatus *status,
                   long long generation, float *__restrict__ out, const float *__restrict__ gt,
                   float *__restrict__ loss_part, float *__restrict__ partials,
                   float *__restrict__ gslots, size_t gslot_n, int stamp)
@@ -228,9 +228,9 @@ fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *
     __shared__ float4 s_v[256];   // the tile's loss gradient
     __shared__ int s_w[4];
     int *s_sorted = pool + FWD_INTS;
-    const int n_raw = fwd_tile<FINALIZE, true, 1, PPL, true>(
+    const int n_raw = fwd_tile<FINALIZE, true, 1, PPL, true, PACKED>(
         pool, nullptr, s_v, s_sorted, tile_count, tile_len, seg, C, xys, conics, colors, opacity,
-        background, H, W, tiles_x, row0, T, cv, cull, status, generation, out, gt, nullptr,
+        rec, background, H, W, tiles_x, row0, T, cv, cull, status, generation, out, gt, nullptr,
         loss_part, ExtraSets());
     // (every wave is past its last read of the forward's records; the list, the loss gradient
     // and the sorted ids are visible to the whole workgroup)
@@ -311,7 +311,8 @@ static int adan_scalars(const gi2d_adan_hyper *hyper, AdanScalars &h)
 // The projection of the raw parameters (skipped when a chained step has already done it into
 // these outputs) and the binning bookkeeping of a fitting iteration.
 static int fit_project_bin(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
-                           const float *cov_b, const float *opacity, int N, int H, int W,
+                           const float *cov_b, const float *features, const float *opacity, int N,
+                           int H, int W,
                            const gi2d_conv *conv, float *xys, float *depths, int *radii,
                            float *conics, int *num_tiles_hit, void *stream)
 {
@@ -320,9 +321,11 @@ static int fit_project_bin(gi2d_workspace *ws, int kind, const float *xyz, const
                          ws->chain_xys == (const void *)xys && ws->pre_n == N &&
                          ws->pre_tx == tiles_x && ws->pre_ty == tiles_y;
     if (!chained) {
+        ProjExtras ex;
+        ex.opacity = opacity;
+        ex.colors = features;
         int rc = project_impl(kind, true, xyz, cov_a, cov_b, N, H, W, tiles_x, tiles_y, conv, xys,
-                              depths, radii, conics, num_tiles_hit, ws, stream, nullptr, nullptr,
-                              opacity);
+                              depths, radii, conics, num_tiles_hit, ws, stream, ex);
         if (rc != GI2D_OK) return rc;
     }
     return gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
@@ -338,7 +341,7 @@ int gi2d_fit_forward(gi2d_workspace *ws, int kind, const float *xyz, const float
                      float *v_image, float *loss_partials, void *stream)
 {
     if (!ws || (kind != 0 && kind != 1) || !gt_chw) return GI2D_E_INVALID;
-    int rc = fit_project_bin(ws, kind, xyz, cov_a, cov_b, opacity, N, H, W, conv, xys, depths,
+    int rc = fit_project_bin(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys, depths,
                              radii, conics, num_tiles_hit, stream);
     if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
     const int late = rc;
@@ -396,18 +399,21 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
                               st);
         if (rc != GI2D_OK) return rc;
     }
-    const bool chained = chain != nullptr && begin_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y);
+    bool chained = chain != nullptr && begin_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y);
+    if (chained && !ws->no_records && ensure_records(ws, N) != GI2D_OK) {
+        (void)hipGetLastError();
+        chained = false;
+    }
     ChainArgs ch = ChainArgs();
     if (chained) {
         ch.center_bias = conv->center_bias;
-        ch.depths = chain->depths;
-        ch.conics = chain->conics;
-        ch.num_tiles_hit = chain->num_tiles_hit;
-        ch.next_count = ws->alt_count;
-        ch.next_seg = ws->alt_seg;
+        ch.out = ProjOut{chain->xys, chain->depths, chain->radii, chain->conics,
+                         chain->num_tiles_hit};
+        ch.lists = TileLists{ws->alt_count, ws->alt_seg, ws->seg_cap, ws->bin_row0, ws->bin_row1};
         ch.cull.opacity = ws->cull ? opacity : nullptr;
         ch.cull.alpha_min = conv->alpha_min;
         ch.cull.pixel_offset = conv->pixel_offset;
+        if (!ws->no_records) ch.rec = RecordSink{ws->d_rec, opacity, conv->alpha_cap};
         ch.status = ws->d_status;
         ch.h_status = ws->h_status_dev;
         ch.generation = ws->generation;
@@ -422,14 +428,23 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
     // launch spreads over every CU (as in the projection kernels)
     const int threads = chained ? PG_THREADS : 256;
     const dim3 grid(cdiv(N, threads)), block(threads);
+    {
+    Probe probe(ws, GI2D_PROBE_FIT_TAIL, st);
     if (kind == 0 && chained) fit_tail_kernel<false, true><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
     else if (kind == 0) fit_tail_kernel<false, false><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
     else if (chained) fit_tail_kernel<true, true><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
     else fit_tail_kernel<true, false><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
+    }
 #undef GI2D_TAIL_ARGS
     rc = launch_status();
-    if (rc == GI2D_OK && chained)
+    if (rc == GI2D_OK && chained) {
         commit_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y, kind, chain->xys);
+        // the records the tail wrote are the next frame's, for these tensors
+        ws->rec_valid = ch.rec.rec != nullptr;
+        ws->rec_xys = chain->xys;
+        ws->rec_colors = features;
+        ws->rec_opacity = opacity;
+    }
     return rc;
 }
 
@@ -475,7 +490,7 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
     if (N > 0 && (!xyz || !cov_a || (kind == 1 && !cov_b) || !features || !opacity))
         return GI2D_E_INVALID;
     if (conv && conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
-    int rc = fit_project_bin(ws, kind, xyz, cov_a, cov_b, opacity, N, H, W, conv, xys, depths,
+    int rc = fit_project_bin(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys, depths,
                              radii, conics, num_tiles_hit, stream);
     if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
     const int late = rc;
@@ -492,21 +507,34 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
     if (rc != GI2D_OK) return rc;
     rc = next_bwd_stamp(ws, st);
     if (rc != GI2D_OK) return rc;
+    const bool packed = ws->rec_valid && ws->rec_xys == (const void *)xys &&
+                        ws->rec_colors == (const void *)features &&
+                        ws->rec_opacity == (const void *)opacity;
 #define GI2D_FIT_RASTER_ARGS ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap, xys, radii, conics, \
-                             features, opacity, background, H, W, ws->tiles_x, ws->tiles_y,      \
+                             features, opacity, ws->d_rec, background, H, W, ws->tiles_x,        \
+                             ws->tiles_y,                                                        \
                              ws->bin_row0, T, *conv, ws->cull, ws->d_status, ws->generation,     \
                              image, gt_chw, loss_partials, ws->d_partials, ws->d_gslots,         \
                              (size_t)ws->slot_cap, ws->bwd_stamp
     const bool one_wave = sparse_frame(ws, T);
+#define GI2D_FIT_RASTER(FIN, PK)                                                         \
+    do {                                                                                 \
+        if (one_wave) fit_raster_kernel<FIN, 4, PK><<<T, 64, 0, st>>>(GI2D_FIT_RASTER_ARGS); \
+        else fit_raster_kernel<FIN, 1, PK><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);         \
+    } while (0)
+    {
+    Probe probe(ws, GI2D_PROBE_FIT_RASTER, st);
     if (ws->lists_raw) {
-        if (one_wave) fit_raster_kernel<true, 4><<<T, 64, 0, st>>>(GI2D_FIT_RASTER_ARGS);
-        else fit_raster_kernel<true, 1><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);
+        if (packed) GI2D_FIT_RASTER(true, true);
+        else GI2D_FIT_RASTER(true, false);
         ws->lists_raw = false;
         ws->counters_dirty = false;
     } else {
-        if (one_wave) fit_raster_kernel<false, 4><<<T, 64, 0, st>>>(GI2D_FIT_RASTER_ARGS);
-        else fit_raster_kernel<false, 1><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);
+        if (packed) GI2D_FIT_RASTER(false, true);
+        else GI2D_FIT_RASTER(false, false);
     }
+    }
+#undef GI2D_FIT_RASTER
 #undef GI2D_FIT_RASTER_ARGS
     rc = launch_status();
     if (rc != GI2D_OK) return rc;

@@ -22,16 +22,27 @@ struct gi2d_workspace {
     int64_t bwd_serial = 0;     // backward pass-1 launches so far
     int bwd_stamp = 0;          // stamp of the latest one (1 .. INT_MAX), 0 = none yet
     int tiles_x = 0, tiles_y = 0, n_binned = 0;
+    int frames = 1;                  // frames of the current lists (a batch: frames x tiles lists)
     int row0 = 0, row1 = INT_MAX;    // tile rows requested by the caller (a band)
     int bin_row0 = 0, bin_row1 = 0;  // tile rows of the current lists
     bool counters_dirty = false;     // counters may be non-zero
     bool lists_raw = false;          // lists filled but not yet sorted / finalised
     bool lists_valid = false;        // lists belong to the binning that (tiles_x, ...) describe
     bool prefilled = false;          // project_*_fwd filled the lists for the shape below
-    int pre_n = 0, pre_tx = 0, pre_ty = 0, pre_r0 = 0, pre_r1 = 0;
+    int pre_n = 0, pre_tx = 0, pre_ty = 0, pre_r0 = 0, pre_r1 = 0, pre_frames = 1;
+    // The rasteriser's per-Gaussian records (projection.h), written by a projection that knew
+    // the colours and opacities; valid for exactly these tensors of the current binning.
+    float *d_rec = nullptr;
+    int64_t rec_cap = 0;             // Gaussians the buffer holds
+    bool rec_valid = false;
+    const void *rec_xys = nullptr, *rec_colors = nullptr, *rec_opacity = nullptr;
     int cull = 1;
     int raster_ppl = 0;  // 0 = choose by tile count
     int min_seg_cap = 64;
+    // instrumentation (gi2d_workspace_set_probe): events recorded around one kind of launch
+    int probe_kernel = 0;
+    hipEvent_t probe_begin = nullptr, probe_end = nullptr;
+    int no_records = 0;  // 1: projections never write the rasteriser's records (no-alloc path)
     // Second list set (same tiles_cap x seg_cap): the fitting tail fills it with the NEXT
     // iteration's lists while it still reads the current ones; the sets then swap roles.
     int *alt_count = nullptr, *alt_len = nullptr, *alt_seg = nullptr;
@@ -73,6 +84,25 @@ struct DeviceGuard {
 };
 }  // namespace
 
+// Records the workspace's probe events right before / after a launch of the probed kind
+// (scope = the launch statement).
+struct Probe {
+    hipEvent_t end = nullptr;
+    hipStream_t st = nullptr;
+    Probe(const gi2d_workspace *ws, int kernel, hipStream_t stream)
+    {
+        if (ws && ws->probe_kernel == kernel && ws->probe_begin && ws->probe_end) {
+            (void)hipEventRecord(ws->probe_begin, stream);
+            end = ws->probe_end;
+            st = stream;
+        }
+    }
+    ~Probe()
+    {
+        if (end) (void)hipEventRecord(end, st);
+    }
+};
+
 // Further colour sets and the optional planar output of the forward rasteriser.
 struct ExtraSets {
     const float *colors[2];  // [N,3] each
@@ -100,29 +130,52 @@ static inline bool sparse_frame(const gi2d_workspace *ws, int T)
     return T >= GI2D_PPL4_MIN_TILES && ws->h_status[0] <= 64;
 }
 
+// tile lists of the current binning: all frames / one frame
+static inline int ws_tiles_per_frame(const gi2d_workspace *ws)
+{
+    return ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+}
+static inline int ws_tiles(const gi2d_workspace *ws) { return ws->frames * ws_tiles_per_frame(ws); }
+
 // lists.hip
 int ensure_lists(gi2d_workspace *ws, int T, int C);
+int ensure_records(gi2d_workspace *ws, int64_t count);
+int bin_tiles_impl(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
+                   int tiles_y, int flags, void *stream, int frames);
 int wanted_cap(const gi2d_workspace *ws, long long seen);
 int zero_counters(gi2d_workspace *ws, hipStream_t st);
 int finalize_lists(gi2d_workspace *ws, hipStream_t st);
-int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream_t st);
+int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int frames, hipStream_t st);
 bool begin_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y);
 void commit_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int kind,
                           const void *xys);
 
 // project.hip
+// Optional parts of a projection call.  codec: the inputs are coded attributes (means / cov_a /
+// cov_b unused) and the decoded colours go to colors_out.  opacity: the opacities the rasteriser
+// will use -- lets the lists hold only tiles a Gaussian's support can touch; with colors (or a
+// codec) as well, the projection also writes the rasteriser's per-Gaussian records.  frames: a
+// batch of that many frames of N Gaussians each ([frames][N][...] tensors).
+struct ProjExtras {
+    const gi2d_codec *codec = nullptr;
+    float *colors_out = nullptr;
+    const float *opacity = nullptr;
+    const float *colors = nullptr;
+    int frames = 1;
+};
 int project_impl(int kind, bool raw, const float *means, const float *cov_a, const float *cov_b,
                  int N, int H, int W, int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
                  float *depths, int *radii, float *conics, int *num_tiles_hit, gi2d_workspace *ws,
-                 void *stream, const gi2d_codec *codec = nullptr, float *colors_out = nullptr,
-                 const float *cull_opacity = nullptr);
+                 void *stream, const ProjExtras &ex = ProjExtras());
 
 // raster_fwd.hip
-int check_raster_args(gi2d_workspace *ws, int N, int H, int W, const gi2d_conv *conv);
+int check_raster_args(gi2d_workspace *ws, int N, int H, int W, const gi2d_conv *conv,
+                      int frames = 1);
 int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *conics, const float *colors,
                     const float *opacity, const float *background, int N, int H, int W,
                     const gi2d_conv *conv, float *out_img, const float *gt, float *v_img,
-                    float *loss_part, void *stream, int sets = 1, ExtraSets extra = ExtraSets());
+                    float *loss_part, void *stream, int sets = 1, ExtraSets extra = ExtraSets(),
+                    int frames = 1);
 
 // raster_bwd.hip
 int ensure_bwd_buffers(gi2d_workspace *ws, int N);

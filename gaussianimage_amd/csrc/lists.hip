@@ -2,19 +2,26 @@
 // policy, binning from caller-made tensors, list read-back; plus version / error strings.
 #include "host.h"
 #include "tiles.h"
+#define REC_FLOATS_HOST 12  // = REC_FLOATS of projection.h
 
 // Binning from caller-made xys / radii (no projection in front of it).
+// (gridDim.y frames of N Gaussians, each with its own run of tiles_per_frame lists)
 __global__ __launch_bounds__(256) void bin_tiles_kernel(const float *__restrict__ xys,
                                                          const int *__restrict__ radii, int N,
                                                          int tiles_x, int tiles_y, int row0,
                                                          int row1, int *tile_count, int *seg, int C,
                                                          const DevStatus *status,
                                                          volatile long long *h_status,
-                                                         long long generation)
+                                                         long long generation, int tiles_per_frame)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) publish_status(status, h_status, generation);
+    const int f = blockIdx.y;
+    if (g == 0 && f == 0) publish_status(status, h_status, generation);
     if (g >= N) return;
+    xys += (size_t)f * 2 * N;
+    radii += (size_t)f * N;
+    tile_count += (size_t)f * tiles_per_frame * CNT_STRIDE;
+    seg += (size_t)f * tiles_per_frame * C;
     const int r = radii[g];
     const float cx = xys[2 * g], cy = xys[2 * g + 1];
     if (r <= 0) return;
@@ -142,7 +149,7 @@ int zero_counters(gi2d_workspace *ws, hipStream_t st)
 int finalize_lists(gi2d_workspace *ws, hipStream_t st)
 {
     if (!ws->lists_raw) return GI2D_OK;
-    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    const int T = ws_tiles(ws);
     if (T > 0) {
         finalize_tiles_kernel<<<T, WAVE, 0, st>>>(ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap,
                                                   ws->d_status, ws->generation);
@@ -155,25 +162,44 @@ int finalize_lists(gi2d_workspace *ws, hipStream_t st)
 }
 
 // True when the next binning of this shape must learn its list lengths synchronously.
-static bool shape_is_new(const gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int r0, int r1)
+static bool shape_is_new(const gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int r0, int r1,
+                         int frames = 1)
 {
     return ws->seg_cap == 0 || ws->generation == 0 || N != ws->n_binned ||
            tiles_x != ws->tiles_x || tiles_y != ws->tiles_y || r0 != ws->bin_row0 ||
-           r1 != ws->bin_row1;
+           r1 != ws->bin_row1 || frames != ws->frames;
+}
+
+// The per-Gaussian record buffer for `count` Gaussians; the device is current.
+int ensure_records(gi2d_workspace *ws, int64_t count)
+{
+    if (ws->rec_cap >= count) return GI2D_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (ws->d_rec) (void)hipFree(ws->d_rec);
+    ws->d_rec = nullptr;
+    ws->rec_cap = 0;
+    ws->rec_valid = false;
+    HIP_TRY(hipMalloc(&ws->d_rec, sizeof(float) * REC_FLOATS_HOST * (size_t)count));
+    ws->rec_cap = count;
+    return GI2D_OK;
 }
 
 // Prepares ws for a projection that also fills the tile lists.  Leaves ws->prefilled false when
 // the shape is new (the lists' capacity is unknown): gi2d_bin_tiles then bins synchronously.
-int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream_t st)
+int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int frames, hipStream_t st)
 {
     const int r0 = min(ws->row0, tiles_y), r1 = min(ws->row1, tiles_y);
-    const int T = (r1 - r0) * tiles_x;
+    if (frames < 1 || (int64_t)(r1 - r0) * tiles_x * frames >= (int64_t)INT_MAX / 2)
+        return GI2D_E_INVALID;
+    if (frames > 1 && (r0 != 0 || r1 != tiles_y)) return GI2D_E_INVALID;  // a batch of whole frames
+    const int T = (r1 - r0) * tiles_x * frames;
     ws->prefilled = false;
+    ws->rec_valid = false;
     ws->chain_pending = false;  // a new projection replaces whatever a chained step prepared
-    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1)) return GI2D_OK;
+    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1, frames)) return GI2D_OK;
     int rc = ensure_lists(ws, max(1, T), wanted_cap(ws, ws->h_status[0]));
     if (rc != GI2D_OK) return rc;
-    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1)) return GI2D_OK;  // reallocated
+    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1, frames)) return GI2D_OK;  // reallocated
     if (ws->counters_dirty) {
         rc = zero_counters(ws, st);
         if (rc != GI2D_OK) return rc;
@@ -187,6 +213,7 @@ int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream
     ws->pre_ty = tiles_y;
     ws->pre_r0 = r0;
     ws->pre_r1 = r1;
+    ws->pre_frames = frames;
     return GI2D_OK;
 }
 
@@ -197,7 +224,7 @@ int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, hipStream
 bool begin_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y)
 {
     const int r0 = min(ws->row0, tiles_y), r1 = min(ws->row1, tiles_y);
-    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1)) return false;
+    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1)) return false;  // (one frame)
     if (ws->counters_dirty || ws->lists_raw || !ws->lists_valid || ws->seg_cap == 0) return false;
     if (wanted_cap(ws, ws->h_status[0]) > ws->seg_cap) return false;
     if (!ws->alt_count) {
@@ -235,6 +262,7 @@ void commit_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, i
     ws->pre_ty = tiles_y;
     ws->pre_r0 = min(ws->row0, tiles_y);
     ws->pre_r1 = min(ws->row1, tiles_y);
+    ws->pre_frames = 1;
     ws->chain_pending = true;
     ws->chain_kind = kind;
     ws->chain_xys = xys;
@@ -243,6 +271,11 @@ void commit_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, i
 extern "C" {
 
 int gi2d_version(void) { return GI2D_VERSION; }
+
+#ifndef GI2D_BUILD_ID
+#define GI2D_BUILD_ID "unknown"
+#endif
+const char *gi2d_build_id(void) { return GI2D_BUILD_ID; }
 
 const char *gi2d_error_string(int status)
 {
@@ -304,6 +337,7 @@ int gi2d_workspace_destroy(gi2d_workspace *ws)
     if (ws->d_partials) (void)hipFree(ws->d_partials);
     free_alt_lists(ws);
     if (ws->d_gslots) (void)hipFree(ws->d_gslots);
+    if (ws->d_rec) (void)hipFree(ws->d_rec);
     if (ws->d_status) (void)hipFree(ws->d_status);
     if (ws->h_status) (void)hipHostFree(ws->h_status);
     delete ws;
@@ -332,12 +366,26 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
         case GI2D_OPT_DROP_PENDING:
             ws->chain_pending = false;
             return GI2D_OK;
+        case GI2D_OPT_RECORDS:
+            ws->no_records = value ? 0 : 1;
+            ws->rec_valid = false;
+            return GI2D_OK;
         case GI2D_OPT_BWD_SERIAL:
             if (value < 0) return GI2D_E_INVALID;
             ws->bwd_serial = value;
             return GI2D_OK;
         default: return GI2D_E_INVALID;
     }
+}
+
+int gi2d_workspace_set_probe(gi2d_workspace *ws, int kernel, void *begin_event, void *end_event)
+{
+    if (!ws || kernel < 0 || kernel > GI2D_PROBE_FIT_TAIL) return GI2D_E_INVALID;
+    const bool on = kernel != 0 && begin_event && end_event;
+    ws->probe_kernel = on ? kernel : 0;
+    ws->probe_begin = on ? (hipEvent_t)begin_event : nullptr;
+    ws->probe_end = on ? (hipEvent_t)end_event : nullptr;
+    return GI2D_OK;
 }
 
 int gi2d_workspace_set_rows(gi2d_workspace *ws, int row_begin, int row_end)
@@ -348,7 +396,7 @@ int gi2d_workspace_set_rows(gi2d_workspace *ws, int row_begin, int row_end)
     return GI2D_OK;
 }
 
-int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[8])
+int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[10])
 {
     if (!ws || !info) return GI2D_E_INVALID;
     info[0] = ws->seg_cap;
@@ -359,12 +407,14 @@ int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[8])
     info[5] = ws->n_binned;
     info[6] = ws->bin_row0;
     info[7] = ws->bin_row1;
+    info[8] = ws->frames;
+    info[9] = ws->rec_valid ? 1 : 0;
     return GI2D_OK;
 }
 
 // Fills the lists from xys / radii with the standalone kernel.
 static int launch_bin(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
-                      int tiles_y, int r0, int r1, hipStream_t st)
+                      int tiles_y, int r0, int r1, int frames, hipStream_t st)
 {
     int rc = GI2D_OK;
     if (ws->counters_dirty) {
@@ -372,23 +422,33 @@ static int launch_bin(gi2d_workspace *ws, const float *xys, const int *radii, in
         if (rc != GI2D_OK) return rc;
     }
     ws->counters_dirty = true;
-    bin_tiles_kernel<<<max(1, cdiv(N, PG_THREADS)), PG_THREADS, 0, st>>>(
+    bin_tiles_kernel<<<dim3(max(1, cdiv(N, PG_THREADS)), frames), PG_THREADS, 0, st>>>(
         xys, radii, N, tiles_x, tiles_y, r0, r1, ws->d_count, ws->d_seg, ws->seg_cap,
-        ws->d_status, ws->h_status_dev, ws->generation);
+        ws->d_status, ws->h_status_dev, ws->generation, (r1 - r0) * tiles_x);
     return launch_status();
 }
 
 int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
                    int tiles_y, int flags, void *stream)
 {
-    if (!ws || N < 0 || tiles_x < 1 || tiles_y < 1) return GI2D_E_INVALID;
-    if ((int64_t)tiles_x * tiles_y >= (int64_t)INT_MAX / 2) return GI2D_E_INVALID;
+    return bin_tiles_impl(ws, xys, radii, N, tiles_x, tiles_y, flags, stream, 1);
+}
+
+}  // extern "C"
+
+// gi2d_bin_tiles for `frames` frames of N Gaussians each (xys / radii: [frames][N][...]).
+int bin_tiles_impl(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
+                   int tiles_y, int flags, void *stream, int frames)
+{
+    if (!ws || N < 0 || tiles_x < 1 || tiles_y < 1 || frames < 1) return GI2D_E_INVALID;
+    if ((int64_t)tiles_x * tiles_y * frames >= (int64_t)INT_MAX / 2) return GI2D_E_INVALID;
     if (N > 0 && (!xys || !radii)) return GI2D_E_INVALID;
     DeviceGuard guard(ws->device);
     if (!guard.ok) return GI2D_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const int r0 = min(ws->row0, tiles_y), r1 = min(ws->row1, tiles_y);
-    const int T = (r1 - r0) * tiles_x;
+    if (frames > 1 && (r0 != 0 || r1 != tiles_y)) return GI2D_E_INVALID;
+    const int T = (r1 - r0) * tiles_x * frames;
     const bool nogrow = (flags & GI2D_BIN_NOGROW) != 0;
     bool sync = (flags & GI2D_BIN_SYNC) != 0;
     bool prev_overflow = false;
@@ -400,16 +460,19 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     }
 
     bool prefilled = ws->prefilled && ws->pre_n == N && ws->pre_tx == tiles_x &&
-                     ws->pre_ty == tiles_y && ws->pre_r0 == r0 && ws->pre_r1 == r1;
+                     ws->pre_ty == tiles_y && ws->pre_r0 == r0 && ws->pre_r1 == r1 &&
+                     ws->pre_frames == frames;
     ws->prefilled = false;
     ws->chain_pending = false;
     if (!(flags & GI2D_BIN_COUNTED)) prefilled = false;
+    // records stay valid only for lists the same projection filled
+    if (!prefilled || ws->rec_xys != (const void *)xys) ws->rec_valid = false;
 
     if (!prefilled) {
         // Size the lists.  Steady state needs no synchronisation: the capacity keeps a 2x
         // margin over the largest per-tile count seen from completed frames.  A new problem
         // shape says nothing about its counts: learn them once, synchronously.
-        if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1) && !nogrow) sync = true;
+        if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1, frames) && !nogrow) sync = true;
         if (nogrow) {
             if (T > ws->tiles_cap || ws->seg_cap == 0) return GI2D_E_CAPACITY;
         } else {
@@ -421,11 +484,12 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     ws->tiles_x = tiles_x;
     ws->tiles_y = tiles_y;
     ws->n_binned = N;
+    ws->frames = frames;
     ws->bin_row0 = r0;
     ws->bin_row1 = r1;
     ws->lists_valid = false;
     if (!prefilled) {
-        int rc = launch_bin(ws, xys, radii, N, tiles_x, tiles_y, r0, r1, st);
+        int rc = launch_bin(ws, xys, radii, N, tiles_x, tiles_y, r0, r1, frames, st);
         if (rc != GI2D_OK) return rc;
     }
     ws->lists_raw = true;
@@ -468,7 +532,7 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
             if (rc != GI2D_OK) return rc;
             ws->tiles_x = tiles_x;
             ws->tiles_y = tiles_y;
-            rc = launch_bin(ws, xys, radii, N, tiles_x, tiles_y, r0, r1, st);
+            rc = launch_bin(ws, xys, radii, N, tiles_x, tiles_y, r0, r1, frames, st);
             if (rc != GI2D_OK) return rc;
             ws->lists_raw = true;
             ws->lists_valid = true;
@@ -476,6 +540,8 @@ int gi2d_bin_tiles(gi2d_workspace *ws, const float *xys, const int *radii, int N
     }
     return prev_overflow ? GI2D_E_PREV_OVERFLOW : GI2D_OK;
 }
+
+extern "C" {
 
 int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_capacity,
                    void *stream)
@@ -486,7 +552,7 @@ int gi2d_copy_bins(gi2d_workspace *ws, int *tile_offsets, int *ids, int64_t ids_
     hipStream_t st = (hipStream_t)stream;
     int rc = finalize_lists(ws, st);
     if (rc != GI2D_OK) return rc;
-    const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
+    const int T = ws_tiles(ws);
     const int C = ws->seg_cap;
     int *h_len = (int *)malloc(sizeof(int) * ((size_t)T + 1));
     int *h_off = (int *)malloc(sizeof(int) * ((size_t)T + 1));

@@ -26,19 +26,60 @@
 // projection and tile binning (one lane per Gaussian)
 // ------------------------------------------------------------------------------------------
 
+// What every projection kernel takes besides its inputs.  A launch covers `gridDim.y` frames of
+// N Gaussians each (a batch of independent frames of one shape): every per-Gaussian tensor is
+// [frames][N][...], every frame has its own run of `tiles_per_frame` tile lists, and ids in the
+// lists are frame-local.
+struct ProjArgs {
+    int N, H, W, tiles_x, tiles_y;
+    float center_bias;
+    ProjOut out;
+    TileLists lists;
+    ListCull cull;
+    RecordSink rec;
+    const float *rec_colors;  // [N,3] colours for the records (the decode kernel has its own)
+    const DevStatus *status;
+    volatile long long *h_status;
+    long long generation;
+    int tiles_per_frame;
+};
+
+// Moves every per-Gaussian and per-tile pointer to frame f.
+__device__ __forceinline__ void to_frame(ProjArgs &a, int f)
+{
+    const size_t n = (size_t)f * a.N;
+    a.out.xys += 2 * n;
+    a.out.depths += n;
+    a.out.radii += n;
+    a.out.conics += 3 * n;
+    a.out.num_tiles_hit += n;
+    if (a.lists.tile_count != nullptr) {
+        const size_t t = (size_t)f * a.tiles_per_frame;
+        a.lists.tile_count += t * CNT_STRIDE;
+        a.lists.seg += t * a.lists.C;
+    }
+    if (a.cull.opacity != nullptr) a.cull.opacity += n;
+    if (a.rec.rec != nullptr) {
+        a.rec.rec += n * REC_FLOATS;
+        a.rec.opacity += n;
+        if (a.rec_colors != nullptr) a.rec_colors += 3 * n;
+    }
+}
+
 // RAW = the model's raw parameters come in and its activations are applied here:
 // means = tanh(_xyz), L = _cholesky + (0.5, 0, 0.5) (gaussianimage_cholesky.py:62,74,42).
 template <bool RAW>
 __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
-    const float *__restrict__ means, const float *__restrict__ L, int N, int H, int W, int tiles_x,
-    int tiles_y, float center_bias, float *__restrict__ xys, float *__restrict__ depths,
-    int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count, int *seg, int C, int row0, int row1, ListCull cull, const DevStatus *status,
-    volatile long long *h_status, long long generation)
+    const float *__restrict__ means, const float *__restrict__ L, ProjArgs a)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
-    if (g >= N) return;
+    const int f = blockIdx.y;
+    if (g == 0 && f == 0 && a.lists.tile_count != nullptr)
+        publish_status(a.status, a.h_status, a.generation);
+    if (g >= a.N) return;
+    to_frame(a, f);
+    means += (size_t)f * 2 * a.N;
+    L += (size_t)f * 3 * a.N;
     float l11 = L[3 * g], l21 = L[3 * g + 1], l22 = L[3 * g + 2];
     float mx = means[2 * g], my = means[2 * g + 1];
     if (RAW) {
@@ -50,8 +91,14 @@ __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
     float sxx = l11 * l11;
     float sxy = l11 * l21;
     float syy = l21 * l21 + l22 * l22;
-    project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths, radii,
-                 conics, num_tiles_hit, tile_count, seg, C, row0, row1, cull);
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    if (a.rec.rec != nullptr) {
+        cr = a.rec_colors[3 * g];
+        cg = a.rec_colors[3 * g + 1];
+        cb = a.rec_colors[3 * g + 2];
+    }
+    project_tail(g, mx, my, sxx, sxy, syy, a.H, a.W, a.tiles_x, a.tiles_y, a.center_bias, a.out,
+                 a.lists, a.cull, a.rec, cr, cg, cb);
 }
 
 // RAW: means = tanh(_xyz), scales = |_scaling + 0.5|, rotation = sigmoid(_rotation) * 2 * pi
@@ -59,15 +106,17 @@ __global__ __launch_bounds__(256) void project_cholesky_fwd_kernel(
 template <bool RAW>
 __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     const float *__restrict__ means, const float *__restrict__ scales,
-    const float *__restrict__ rot, int N, int H, int W, int tiles_x, int tiles_y,
-    float center_bias, float *__restrict__ xys, float *__restrict__ depths,
-    int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count, int *seg, int C, int row0, int row1, ListCull cull, const DevStatus *status,
-    volatile long long *h_status, long long generation)
+    const float *__restrict__ rot, ProjArgs a)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
-    if (g >= N) return;
+    const int f = blockIdx.y;
+    if (g == 0 && f == 0 && a.lists.tile_count != nullptr)
+        publish_status(a.status, a.h_status, a.generation);
+    if (g >= a.N) return;
+    to_frame(a, f);
+    means += (size_t)f * 2 * a.N;
+    scales += (size_t)f * 2 * a.N;
+    rot += (size_t)f * a.N;
     float theta = rot[g];
     float s1 = scales[2 * g], s2 = scales[2 * g + 1];
     float mx = means[2 * g], my = means[2 * g + 1];
@@ -84,8 +133,14 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
     float sxx = c * c * q1 + s * s * q2;
     float sxy = c * s * (q1 - q2);
     float syy = s * s * q1 + c * c * q2;
-    project_tail(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths, radii,
-                 conics, num_tiles_hit, tile_count, seg, C, row0, row1, cull);
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    if (a.rec.rec != nullptr) {
+        cr = a.rec_colors[3 * g];
+        cg = a.rec_colors[3 * g + 1];
+        cb = a.rec_colors[3 * g + 2];
+    }
+    project_tail(g, mx, my, sxx, sxy, syy, a.H, a.W, a.tiles_x, a.tiles_y, a.center_bias, a.out,
+                 a.lists, a.cull, a.rec, cr, cg, cb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -159,18 +214,16 @@ __global__ __launch_bounds__(256) void decode_params_kernel(gi2d_codec cd, int N
 }
 
 // Decode fused into the projection: the frame's first launch reads the coded attributes, leaves
-// the decoded colours for the rasteriser and fills the tile lists.
+// the decoded colours for the rasteriser and fills the tile lists.  (One frame per launch.)
 template <bool RS>
-__global__ __launch_bounds__(256) void project_decode_fwd_kernel(
-    gi2d_codec cd, float *__restrict__ colors, int N, int H, int W, int tiles_x, int tiles_y,
-    float center_bias, float *__restrict__ xys, float *__restrict__ depths,
-    int *__restrict__ radii, float *__restrict__ conics, int *__restrict__ num_tiles_hit,
-    int *tile_count, int *seg, int C, int row0, int row1, ListCull cull, const DevStatus *status,
-    volatile long long *h_status, long long generation)
+__global__ __launch_bounds__(256) void project_decode_fwd_kernel(gi2d_codec cd,
+                                                                 float *__restrict__ colors,
+                                                                 ProjArgs a)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0 && tile_count != nullptr) publish_status(status, h_status, generation);
-    if (g >= N) return;
+    if (g == 0 && a.lists.tile_count != nullptr)
+        publish_status(a.status, a.h_status, a.generation);
+    if (g >= a.N) return;
     const DecodedGaussian d = decode_gaussian<RS>(cd, g);
     colors[3 * g] = d.col[0];
     colors[3 * g + 1] = d.col[1];
@@ -188,8 +241,8 @@ __global__ __launch_bounds__(256) void project_decode_fwd_kernel(
         sxy = d.a0 * d.a1;
         syy = d.a1 * d.a1 + d.a2 * d.a2;
     }
-    project_tail(g, d.mx, d.my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias, xys, depths,
-                 radii, conics, num_tiles_hit, tile_count, seg, C, row0, row1, cull);
+    project_tail(g, d.mx, d.my, sxx, sxy, syy, a.H, a.W, a.tiles_x, a.tiles_y, a.center_bias,
+                 a.out, a.lists, a.cull, a.rec, d.col[0], d.col[1], d.col[2]);
 }
 
 __global__ __launch_bounds__(256) void project_cholesky_bwd_kernel(
@@ -285,18 +338,18 @@ static int check_codec(int kind, const gi2d_codec *cd, int N)
     return GI2D_OK;
 }
 
-// codec != NULL: the inputs are the coded attributes (means / cov_a / cov_b unused) and the
-// decoded colours are written to colors_out.
-int project_impl(int kind, bool raw, const float *means, const float *cov_a,
-                        const float *cov_b, int N, int H, int W, int tiles_x, int tiles_y,
-                        const gi2d_conv *conv, float *xys, float *depths, int *radii,
-                        float *conics, int *num_tiles_hit, gi2d_workspace *ws, void *stream,
-                        const gi2d_codec *codec, float *colors_out, const float *cull_opacity)
+int project_impl(int kind, bool raw, const float *means, const float *cov_a, const float *cov_b,
+                 int N, int H, int W, int tiles_x, int tiles_y, const gi2d_conv *conv, float *xys,
+                 float *depths, int *radii, float *conics, int *num_tiles_hit, gi2d_workspace *ws,
+                 void *stream, const ProjExtras &ex)
 {
+    const gi2d_codec *codec = ex.codec;
+    const int frames = ex.frames;
+    if (frames < 1 || (codec && frames != 1)) return GI2D_E_INVALID;
     if (codec) {
         int rcc = check_codec(kind, codec, N);
         if (rcc != GI2D_OK) return rcc;
-        if (N > 0 && !colors_out) return GI2D_E_INVALID;
+        if (N > 0 && !ex.colors_out) return GI2D_E_INVALID;
         means = reinterpret_cast<const float *>(codec->xyz_half);
         cov_a = codec->cov_a_code;
         cov_b = codec->cov_b_code;
@@ -310,41 +363,69 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a,
     DeviceGuard guard(ws ? ws->device : -1);
     if (ws) {
         if (!guard.ok) return GI2D_E_INVALID;
-        rc = begin_prefill(ws, N, tiles_x, tiles_y, st);
+        rc = begin_prefill(ws, N, tiles_x, tiles_y, frames, st);
         if (rc != GI2D_OK) return rc;
         fill = ws->prefilled;
+    } else if (frames != 1) {
+        return GI2D_E_INVALID;
     }
     if (N == 0) return GI2D_OK;
-    int *cnt = fill ? ws->d_count : nullptr, *seg = fill ? ws->d_seg : nullptr;
-    const int C = fill ? ws->seg_cap : 0, r0 = fill ? ws->pre_r0 : 0, r1 = fill ? ws->pre_r1 : 0;
-    DevStatus *status = fill ? ws->d_status : nullptr;
-    long long *hs = fill ? ws->h_status_dev : nullptr;
-    const long long gen = fill ? ws->generation : 0;
-    const dim3 grid(cdiv(N, PG_THREADS)), block(PG_THREADS);
+    ProjArgs a = ProjArgs();
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.tiles_x = tiles_x;
+    a.tiles_y = tiles_y;
+    a.center_bias = conv->center_bias;
+    a.out = ProjOut{xys, depths, radii, conics, num_tiles_hit};
     // list culling needs the opacities the rasteriser will use, and can be switched off with the
     // rasteriser's own culling (GI2D_OPT_CULL)
-    ListCull cull = {nullptr, conv->alpha_min, conv->pixel_offset};
-    if (fill && ws->cull) cull.opacity = cull_opacity;
-#define GI2D_PROJ_ARGS N, H, W, tiles_x, tiles_y, conv->center_bias, xys, depths, radii, conics, \
-                       num_tiles_hit, cnt, seg, C, r0, r1, cull, status, hs, gen
+    a.cull = ListCull{nullptr, conv->alpha_min, conv->pixel_offset};
+    if (fill) {
+        a.lists = TileLists{ws->d_count, ws->d_seg, ws->seg_cap, ws->pre_r0, ws->pre_r1};
+        a.status = ws->d_status;
+        a.h_status = ws->h_status_dev;
+        a.generation = ws->generation;
+        a.tiles_per_frame = (ws->pre_r1 - ws->pre_r0) * tiles_x;
+        if (ws->cull) a.cull.opacity = ex.opacity;
+        // the rasteriser's records: only with lists the rasteriser will actually use, and only
+        // when colours and opacities are known now
+        const float *rec_colors = codec ? ex.colors_out : ex.colors;
+        if (ex.opacity && rec_colors && !ws->no_records) {
+            rc = ensure_records(ws, (int64_t)frames * N);
+            if (rc != GI2D_OK) return rc;
+            a.rec = RecordSink{ws->d_rec, ex.opacity, conv->alpha_cap};
+            a.rec_colors = codec ? nullptr : ex.colors;
+        }
+    }
+    const dim3 grid(cdiv(N, PG_THREADS), frames), block(PG_THREADS);
+    {
+    Probe probe(fill ? ws : nullptr, GI2D_PROBE_PROJECT, st);
     if (codec) {
         if (kind == 0)
-            project_decode_fwd_kernel<false><<<grid, block, 0, st>>>(*codec, colors_out, GI2D_PROJ_ARGS);
+            project_decode_fwd_kernel<false><<<grid, block, 0, st>>>(*codec, ex.colors_out, a);
         else
-            project_decode_fwd_kernel<true><<<grid, block, 0, st>>>(*codec, colors_out, GI2D_PROJ_ARGS);
+            project_decode_fwd_kernel<true><<<grid, block, 0, st>>>(*codec, ex.colors_out, a);
     } else if (kind == 0) {
         if (raw)
-            project_cholesky_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, GI2D_PROJ_ARGS);
+            project_cholesky_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, a);
         else
-            project_cholesky_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, GI2D_PROJ_ARGS);
+            project_cholesky_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, a);
     } else {
         if (raw)
-            project_rs_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, cov_b, GI2D_PROJ_ARGS);
+            project_rs_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, cov_b, a);
         else
-            project_rs_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, cov_b, GI2D_PROJ_ARGS);
+            project_rs_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, cov_b, a);
     }
-#undef GI2D_PROJ_ARGS
-    return launch_status();
+    }
+    rc = launch_status();
+    if (rc == GI2D_OK && a.rec.rec != nullptr) {
+        ws->rec_valid = true;
+        ws->rec_xys = xys;
+        ws->rec_colors = codec ? ex.colors_out : ex.colors;
+        ws->rec_opacity = ex.opacity;
+    }
+    return rc;
 }
 
 

@@ -225,6 +225,7 @@ int raster_bwd_pass1(gi2d_workspace *ws, const float *xys, const int *radii,
                       ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, T, *conv, ws->cull,     \
                       v_out, ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap,                   \
                       ws->bwd_stamp
+        Probe probe(ws, GI2D_PROBE_RASTER_BWD, st);
         if (sparse_frame(ws, T))
             rasterize_sum_bwd_wave_kernel<<<T, 64, 0, st>>>(GI2D_BWD_ARGS);
         else
@@ -254,6 +255,7 @@ int gi2d_rasterize_sum_bwd(gi2d_workspace *ws, const float *xys, const int *radi
     hipStream_t st = (hipStream_t)stream;
     rc = raster_bwd_pass1(ws, xys, radii, conics, colors, opacity, N, H, W, conv, v_out, st);
     if (rc != GI2D_OK) return rc;
+    Probe probe(ws, GI2D_PROBE_GATHER, st);
     gather_grads_kernel<<<cdiv(N, 256), 256, 0, st>>>(
         xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, ws->d_len, ws->d_seg,
         ws->seg_cap, ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap, ws->bwd_stamp, v_xys,

@@ -2,14 +2,15 @@
 // and the fused fitting kernel).
 #pragma once
 #include "host.h"
-#include "support.h"
-#include "tiles.h"
+#include "projection.h"
+#include <type_traits>
 
-// LDS words per staged entry: two float4 records, blue, quadrant mask, id.  A workgroup of
-// BATCH lanes holds BATCH entries (11 KB for 256 lanes, 2.75 KB for 64: the small shapes need
-// the small footprint to reach their occupancy); the same words are the sort buffer of a list
-// longer than one batch.
-#define FWD_LDS_INTS_PER_ENTRY 11
+// LDS words per staged entry: three float4 records (the third holds blue and the quadrant mask)
+// and the id.  The records are three arrays of the same 16-byte stride, so that the pair loop
+// reaches all of an entry's words from one address register.  A workgroup of BATCH lanes holds
+// BATCH entries (13 KB for 256 lanes, 3.25 KB for 64: the small shapes need the small footprint
+// to reach their occupancy); the same words are the sort buffer of a list longer than one batch.
+#define FWD_LDS_INTS_PER_ENTRY 13
 
 // L2 = true adds the fitting loop's epilogue (gaussianimage_cholesky.py:83-85,104 with
 // utils.py:24-25): clamp to [0,1], L2 loss against the target (stored [3,H,W] like the model's
@@ -33,11 +34,16 @@
 // (256 / PPL) of ids that this pass sorts (FINALIZE) is also left, sorted, in keep_ids.
 // `smem` holds FWD_LDS_INTS_PER_ENTRY * (256 / PPL) ints (16-byte aligned), `s_x` the extra
 // colour sets' records.  Returns the tile's raw list length.
-template <bool FINALIZE, bool L2, int SETS, int PPL, bool KEEP>
+//
+// PACKED = true: the Gaussians' attributes come from the per-Gaussian records a projection wrote
+// (`rec`, projection.h) -- one 48-byte line per list entry; false: from the separately passed
+// tensors, turned into the same record while staging.  Same bits either way.
+template <bool FINALIZE, bool L2, int SETS, int PPL, bool KEEP, bool PACKED = false>
 __device__ __forceinline__ int fwd_tile(
     int *smem, float4 *s_x, float4 *keep_v, int *keep_ids, int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacity, const float *__restrict__ background, int H, int W,
+    const float *__restrict__ opacity, const float *__restrict__ rec,
+    const float *__restrict__ background, int H, int W,
     int tiles_x,
     int row0, int T, gi2d_conv cv, int cull, DevStatus *status, long long generation,
     float *__restrict__ out, const float *__restrict__ gt, float *__restrict__ v_img,
@@ -46,16 +52,18 @@ __device__ __forceinline__ int fwd_tile(
     static_assert(SETS >= 1 && SETS <= 3 && !(L2 && SETS > 1), "unsupported variant");
     static_assert(PPL == 1 || ((PPL == 2 || PPL == 4) && SETS == 1), "unsupported variant");
     static_assert(!KEEP || L2, "unsupported variant");
+    static_assert(!PACKED || SETS == 1, "unsupported variant");
     constexpr int BATCH = 256 / PPL;            // lanes of the workgroup = entries staged at once
     constexpr int NX = 3 * (SETS - 1);          // extra colour floats per entry
     constexpr int NX4 = (NX + 3) / 4;           // ... in float4 records
     constexpr int FWD_LDS_INTS = FWD_LDS_INTS_PER_ENTRY * BATCH;
     // s_x: record q of entry k of the extra sets at [q*256+k]
     float4 *s_a = reinterpret_cast<float4 *>(smem);         // gx, gy, -0.5*a*log2e, -b*log2e
-    float4 *s_b = reinterpret_cast<float4 *>(smem + 4 * BATCH);  // -0.5*c*log2e, opacity, r, g
-    float *s_c = reinterpret_cast<float *>(smem + 8 * BATCH);    // b
-    int *s_m = smem + 9 * BATCH;                            // quadrant mask (bit = 2*qy + qx)
-    int *s_id = smem + 10 * BATCH;                          // ids of the batch (rank sort)
+    // -0.5*c*log2e, log2(opacity) (plain entries) or opacity (general entries), r, g
+    float4 *s_b = reinterpret_cast<float4 *>(smem + 4 * BATCH);
+    // b, quadrant mask (bit = 2*qy + qx; bit 4 = general entry), -, -
+    float4 *s_c = reinterpret_cast<float4 *>(smem + 8 * BATCH);
+    int *s_id = smem + 12 * BATCH;                          // ids of the batch (rank sort)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_tile(blockIdx.x, T);
     const int tx = t % tiles_x, ty = row0 + t / tiles_x;
@@ -126,13 +134,22 @@ __device__ __forceinline__ int fwd_tile(
             }
         }
         int mask = 0;
+        float blue = 0.f;
         if (tid < n) {
-            const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
-            const float ca = conics[3 * gid], cb = conics[3 * gid + 1], cc = conics[3 * gid + 2];
-            const float op = opacity[gid];
-            s_a[slot] = make_float4(gx, gy, (-0.5f * LOG2E) * ca, (-LOG2E) * cb);
-            s_b[slot] = make_float4((-0.5f * LOG2E) * cc, op, colors[3 * gid], colors[3 * gid + 1]);
-            s_c[slot] = colors[3 * gid + 2];
+            Record R;
+            if (PACKED) {
+                const float4 *src = reinterpret_cast<const float4 *>(rec) + 3 * (size_t)gid;
+                R.r0 = src[0];
+                R.r1 = src[1];
+                R.r2 = src[2];
+            } else {
+                R = make_record(xys[2 * gid], xys[2 * gid + 1], conics[3 * gid], conics[3 * gid + 1],
+                                conics[3 * gid + 2], opacity[gid], cv.alpha_cap, cv.alpha_min,
+                                colors[3 * gid], colors[3 * gid + 1], colors[3 * gid + 2]);
+            }
+            s_a[slot] = R.r0;
+            s_b[slot] = R.r1;
+            blue = R.r2.x;
             if (NX) {
                 float xc[NX4 ? 4 * NX4 : 1];
 #pragma unroll
@@ -143,51 +160,75 @@ __device__ __forceinline__ int fwd_tile(
                     s_x[q * 256 + slot] =
                         make_float4(xc[4 * q], xc[4 * q + 1], xc[4 * q + 2], xc[4 * q + 3]);
             }
+            const int flags = __float_as_int(R.r2.y);
             int x0 = 0, x1 = x_hi, y0 = 0, y1 = y_hi;
-            if (cull) support_rect(gx, gy, ca, cb, cc, op, cv.alpha_min, ox, oy, x0, x1, y0, y1);
+            if (cull)
+                support_rect_from((flags >> 1) & 3, R.r2.z, R.r2.w, R.r0.x, R.r0.y, ox, oy, x0, x1,
+                                  y0, y1);
             if (x0 <= x1 && y0 <= y1) {
                 const int mx = (x0 < 8 ? 1 : 0) | (x1 >= 8 ? 2 : 0);
                 const int my = (y0 < 8 ? 1 : 0) | (y1 >= 8 ? 2 : 0);
                 mask = ((my & 1) ? mx : 0) | ((my & 2) ? (mx << 2) : 0);
             }
+            mask |= (flags & 1) << 4;  // a general entry
         }
-        s_m[slot] = mask;  // lanes past the batch keep slot = tid >= n and store 0
+        // lanes past the batch keep slot = tid >= n and store an empty mask
+        s_c[slot] = make_float4(blue, __int_as_float(mask), 0.f, 0.f);
         __syncthreads();
         for (int c0 = 0; c0 < n; c0 += 64) {
-            const int m = s_m[c0 + lane];
+            const int m = __float_as_int(s_c[c0 + lane].y);
+            const unsigned long long general_bits = __ballot((m >> 4) & 1);
+            // MIXED = false_type: every entry of the chunk is plain (the usual case): the loop
+            // body has no branch at all; otherwise a scalar branch per entry picks the form
+            // (the entry index is uniform over the wave).  Entries are taken in list order
+            // either way.
+            auto chunk = [&](auto mixed) {
 #pragma unroll
-            for (int u = 0; u < PPL; ++u) {
-                unsigned long long bits = __ballot((m >> (wave * PPL + u)) & 1);
-                while (bits) {
-                    const int k = c0 + (int)__builtin_ctzll(bits);
-                    bits &= bits - 1;
-                    const float4 A = s_a[k];
-                    const float4 B = s_b[k];
-                    const float cb = s_c[k];
-                    const float dx = A.x - px[u], dy = A.y - py[u];
-                    // p = -sigma*log2(e) = (A'dx + B'dy)dx + C'dy*dy
-                    const float q = __builtin_fmaf(A.w, dy, A.z * dx);
-                    const float p = __builtin_fmaf(B.x * dy, dy, q * dx);
-                    const float e = __builtin_amdgcn_exp2f(p);
-                    const float alpha = fminf(cv.alpha_cap, B.y * e);
-                    const float w = (p > 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
-                    r[u] = __builtin_fmaf(B.z, w, r[u]);
-                    g[u] = __builtin_fmaf(B.w, w, g[u]);
-                    b[u] = __builtin_fmaf(cb, w, b[u]);
-                    if (NX) {
+                for (int u = 0; u < PPL; ++u) {
+                    unsigned long long bits = __ballot((m >> (wave * PPL + u)) & 1);
+                    while (bits) {
+                        const int kk = (int)__builtin_ctzll(bits);
+                        const int k = c0 + kk;
+                        bits &= bits - 1;
+                        const float4 A = s_a[k];
+                        const float4 B = s_b[k];
+                        const float cb = s_c[k].x;
+                        const float dx = A.x - px[u], dy = A.y - py[u];
+                        const float q = __builtin_fmaf(A.w, dy, A.z * dx);
+                        float w;
+                        if (!decltype(mixed)::value || !((general_bits >> kk) & 1ull)) {
+                            // p = log2(opacity) - sigma*log2(e) <= log2(opacity): alpha = exp2(p)
+                            // <= opacity <= cap, and sigma < 0 cannot happen
+                            const float p =
+                                __builtin_fmaf(B.x * dy, dy, __builtin_fmaf(q, dx, B.y));
+                            const float alpha = __builtin_amdgcn_exp2f(p);
+                            w = alpha < cv.alpha_min ? 0.f : alpha;
+                        } else {
+                            const float p = __builtin_fmaf(B.x * dy, dy, q * dx);
+                            const float e = __builtin_amdgcn_exp2f(p);
+                            const float alpha = fminf(cv.alpha_cap, B.y * e);
+                            w = (p > 0.f || alpha < cv.alpha_min) ? 0.f : alpha;
+                        }
+                        r[u] = __builtin_fmaf(B.z, w, r[u]);
+                        g[u] = __builtin_fmaf(B.w, w, g[u]);
+                        b[u] = __builtin_fmaf(cb, w, b[u]);
+                        if (NX) {
 #pragma unroll
-                        for (int q4 = 0; q4 < NX4; ++q4) {
-                            const float4 X = s_x[q4 * 256 + k];
-                            const float xv[4] = {X.x, X.y, X.z, X.w};
+                            for (int q4 = 0; q4 < NX4; ++q4) {
+                                const float4 X = s_x[q4 * 256 + k];
+                                const float xv[4] = {X.x, X.y, X.z, X.w};
 #pragma unroll
-                            for (int v = 0; v < 4; ++v)
-                                if (4 * q4 + v < NX)
-                                    xacc[4 * q4 + v] =
-                                        __builtin_fmaf(xv[v], w, xacc[4 * q4 + v]);
+                                for (int v = 0; v < 4; ++v)
+                                    if (4 * q4 + v < NX)
+                                        xacc[4 * q4 + v] =
+                                            __builtin_fmaf(xv[v], w, xacc[4 * q4 + v]);
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (general_bits == 0ull) chunk(std::false_type());
+            else chunk(std::true_type());
         }
     }
     // the background is read on the device (three uniform loads) and only when it counts

@@ -33,7 +33,7 @@ GI2D_SINCOS_FN void gi2d_sincos_f32(float theta, float *sin_out, float *cos_out)
     double rd = x - kd * 1.5707963267341256;                 /* pi/2, upper 33 bits */
     rd = rd - kd * 6.0771005065061922e-11;                   /* pi/2 - the constant above */
     const float r = (float)rd;
-    const int quadrant = (int)((long long)kd & 3);
+    const int quadrant = (int)kd & 3; /* |kd| <= 6.4e8: fits */
     const float z = r * r;
     /* sin(r) = r + r*z*(S1 + z*(S2 + z*S3)) */
     float ps = -1.9515295891e-4f * z;

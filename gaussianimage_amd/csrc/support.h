@@ -45,20 +45,28 @@ __device__ __forceinline__ int support_halfwidths(float a, float b, float c, flo
 }
 
 // Pixels of a tile on which a Gaussian can contribute, as inclusive tile-local ranges clipped
-// to [x0,x1] x [y0,y1] (in/out); (ox, oy) is the sample coordinate of the tile's first pixel.
-// Without a usable bound the ranges are left as given.  An empty result has x1 < x0 or y1 < y0.
-__device__ __forceinline__ void support_rect(float gx, float gy, float a, float b, float c,
-                                             float op, float alpha_min, float ox, float oy,
-                                             int &x0, int &x1, int &y0, int &y1)
+// to [x0,x1] x [y0,y1] (in/out), from the bound support_halfwidths gave (kind, hx, hy); (ox, oy)
+// is the sample coordinate of the tile's first pixel.  Without a usable bound the ranges are
+// left as given.  An empty result has x1 < x0 or y1 < y0.
+__device__ __forceinline__ void support_rect_from(int kind, float hx, float hy, float gx, float gy,
+                                                  float ox, float oy, int &x0, int &x1, int &y0,
+                                                  int &y1)
 {
-    float hx = 0.f, hy = 0.f;
-    const int kind = support_halfwidths(a, b, c, op, alpha_min, hx, hy);
     if (kind == 0) {
         x1 = x0 - 1;
     } else if (kind == 1) {
         axis_range(gx, ox, hx, x0, x1, x0, x1);
         axis_range(gy, oy, hy, y0, y1, y0, y1);
     }
+}
+
+__device__ __forceinline__ void support_rect(float gx, float gy, float a, float b, float c,
+                                             float op, float alpha_min, float ox, float oy,
+                                             int &x0, int &x1, int &y0, int &y1)
+{
+    float hx = 0.f, hy = 0.f;
+    const int kind = support_halfwidths(a, b, c, op, alpha_min, hx, hy);
+    support_rect_from(kind, hx, hy, gx, gy, ox, oy, x0, x1, y0, y1);
 }
 
 // Tiles [lo, hi) of one axis whose pixels (sample coordinates j + pixel_offset) can lie within
@@ -72,15 +80,12 @@ __device__ __forceinline__ void axis_tiles(float c, float pixel_offset, float h,
     hi = (int)floorf(jhi * (1.0f / GI2D_BLOCK)) + 1;
 }
 
-// Shrinks a Gaussian's tile box to the tiles its support can touch (same padded bound as
-// support_rect, evaluated in frame coordinates): a tile dropped here holds no pixel on which
-// the Gaussian could reach alpha_min, so listing it would only cost list traffic.
-__device__ __forceinline__ void cull_tile_box(TileBox &box, float cx, float cy, float a, float b,
-                                              float c, float op, float alpha_min,
-                                              float pixel_offset)
+// Shrinks a Gaussian's tile box to the tiles its support can touch (the bound of
+// support_halfwidths, evaluated in frame coordinates): a tile dropped here holds no pixel on
+// which the Gaussian could reach alpha_min, so listing it would only cost list traffic.
+__device__ __forceinline__ void cull_tile_box(TileBox &box, float cx, float cy, int kind, float hx,
+                                              float hy, float pixel_offset)
 {
-    float hx = 0.f, hy = 0.f;
-    const int kind = support_halfwidths(a, b, c, op, alpha_min, hx, hy);
     if (kind == 0) {
         box.x1 = box.x0;
     } else if (kind == 1) {

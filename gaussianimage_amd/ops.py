@@ -11,6 +11,7 @@ current stream and autograd bookkeeping only.
 import ctypes
 import os
 import threading
+import warnings
 
 import torch
 
@@ -82,6 +83,8 @@ class Workspace:
         self.counted_key = None
         self.rows = (0, 2 ** 31 - 1)
         self.sync_binning = os.environ.get("GI2D_SYNC", "0") == "1"
+        self.late_overflows = 0   # GI2D_E_PREV_OVERFLOW reports swallowed by bin()
+        self.strict = False       # True: bin() raises on them instead
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -92,10 +95,11 @@ class Workspace:
                 pass
 
     def info(self):
-        arr = (ctypes.c_int64 * 8)()
+        arr = (ctypes.c_int64 * 10)()
         check(lib.gi2d_workspace_info(self.handle, arr), "gi2d_workspace_info")
         return dict(capacity=arr[0], max_tile_count=arr[1], generation=arr[2], tiles_x=arr[3],
-                    tiles_y=arr[4], num_gaussians=arr[5], row_begin=arr[6], row_end=arr[7])
+                    tiles_y=arr[4], num_gaussians=arr[5], row_begin=arr[6], row_end=arr[7],
+                    frames=arr[8], records=bool(arr[9]))
 
     def set_rows(self, row_begin=0, row_end=2 ** 31 - 1):
         """Restricts binning/rasterisation to tile rows [row_begin, row_end) (a band)."""
@@ -107,6 +111,12 @@ class Workspace:
 
     def set_cull(self, on):
         check(lib.gi2d_workspace_set_option(self.handle, _lib.OPT_CULL, int(bool(on))),
+              "gi2d_workspace_set_option")
+
+    def set_records(self, on):
+        """Per-Gaussian records written by the projections that know colours and opacities
+        (default on); off = the rasteriser always gathers the separate tensors (same bits)."""
+        check(lib.gi2d_workspace_set_option(self.handle, _lib.OPT_RECORDS, int(bool(on))),
               "gi2d_workspace_set_option")
 
     def set_raster_ppl(self, ppl):
@@ -134,7 +144,19 @@ class Workspace:
         rc = lib.gi2d_bin_tiles(self.handle, _ptr(xys), _ptr(radii), xys.shape[0], tiles_x,
                                 tiles_y, flags, _stream(xys.device))
         if rc == _lib.GI2D_E_PREV_OVERFLOW:
-            raise _lib.Gi2dError(rc, "gi2d_bin_tiles")
+            # An EARLIER asynchronous frame outgrew a tile list: those tiles of ITS image were
+            # NaN-filled, the lists have been enlarged since, and the binning asked for now is
+            # complete.  The operators the reference calls never fail this way in the middle of
+            # a fit, so: count it, say it once, go on (strict=True raises instead).
+            self.late_overflows += 1
+            if self.strict:
+                raise _lib.Gi2dError(rc, "gi2d_bin_tiles")
+            if self.late_overflows == 1:
+                warnings.warn("gaussianimage_amd: an earlier frame overflowed a tile list (its "
+                              "overflowed tiles were NaN-filled); the lists have been enlarged. "
+                              "Set GI2D_SYNC=1 to size the lists synchronously in every call.",
+                              RuntimeWarning, stacklevel=3)
+            rc = _lib.GI2D_OK
         check(rc, "gi2d_bin_tiles")
         self.key = key
         self.keep = (xys, radii)
@@ -147,7 +169,7 @@ class Workspace:
         """Exclusive scan of the current list lengths, ``tiles + 1`` ints on the device
         (synchronises); the last entry is the number of intersections."""
         inf = self.info()
-        T = inf["tiles_x"] * (inf["row_end"] - inf["row_begin"])
+        T = inf["frames"] * inf["tiles_x"] * (inf["row_end"] - inf["row_begin"])
         offs = torch.empty(T + 1, dtype=torch.int32, device=self.device)
         check(lib.gi2d_copy_bins(self.handle, _ptr(offs), None, 0, _stream(self.device)),
               "gi2d_copy_bins")
@@ -169,16 +191,21 @@ _WS_LOCK = threading.Lock()
 
 
 def get_workspace(device):
+    """The operators' workspace for the CURRENT STREAM of ``device``.  A workspace serves one
+    stream at a time (its lists are filled by one launch and read by the next), so every stream
+    that calls the operators gets its own: two streams -- two models, an evaluation beside a fit
+    -- never share tile lists.  (Torch hands out a bounded pool of streams per device.)"""
     if not isinstance(device, torch.device):
         device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    ws = _WORKSPACES.get(idx)  # (entries are only ever added)
+    key = (idx, _stream(device) or 0)
+    ws = _WORKSPACES.get(key)  # (entries are only ever added)
     if ws is not None:
         return ws
     with _WS_LOCK:
-        ws = _WORKSPACES.get(idx)
+        ws = _WORKSPACES.get(key)
         if ws is None:
-            ws = _WORKSPACES[idx] = Workspace(torch.device("cuda", idx))
+            ws = _WORKSPACES[key] = Workspace(torch.device("cuda", idx))
         return ws
 
 

@@ -173,12 +173,20 @@ class ShardedFrame:
         return grads
 
 
-def bench_tile_row_sharded(device, rank, world, steps=50, warmup=5, workload="uhd200k"):
-    """Times one 3840x2160 / 200k-Gaussian frame split by tile rows over ``world`` ranks:
-    band rendering alone, and band rendering plus the all-gather (max over ranks)."""
-    from bench import WORKLOADS, make_inputs  # the workload table lives with the bench
-    H, W, N, kind, _ = WORKLOADS[workload]
-    inputs = make_inputs(workload, device, seed=1)  # identical on every rank: replicated
+def bench_tile_row_sharded(device, rank, world, shape, inputs, steps=50, warmup=5, label=""):
+    """Times one frame of ``shape = (H, W, N, kind)`` split by tile rows over ``world`` ranks
+    (``inputs``: the replicated operator inputs on ``device``), max over ranks:
+
+    * the same frame on ONE GPU (every rank renders it whole): the reference point;
+    * band rendering alone -- what a consumer that keeps the bands resident on their GPUs pays
+      (a per-band loss, an encoder that works per band): the figure tile-row scaling is about;
+    * band rendering plus the all-gather of the frame to every rank, and overlapped with the
+      next frame's rendering; plus the gather to rank 0 alone;
+    * the training direction with resident bands: band forward + band backward, then ONE
+      all-reduce of the 8 floats per Gaussian of parameter gradients.
+    """
+    from .pipeline import FramePipeline
+    H, W, N, kind = shape
     frame = ShardedFrame(N, H, W, kind, rank, world, device)
 
     def sync():
@@ -199,6 +207,11 @@ def bench_tile_row_sharded(device, rank, world, steps=50, warmup=5, workload="uh
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) / steps
 
+    v_image = torch.randn(H, W, 3, device=device)
+    whole = FramePipeline(N, H, W, kind=kind, device=device)
+    t_one = timed(lambda: whole.forward(*inputs))
+    t_one_fb = timed(lambda: (whole.forward(*inputs), whole.backward(*inputs, v_image)))
+    del whole
     t_compute = timed(lambda: frame.render_band(*inputs))
     t_total = timed(lambda: frame.render(*inputs))
     pending = []
@@ -216,9 +229,6 @@ def bench_tile_row_sharded(device, rank, world, steps=50, warmup=5, workload="uh
         if w is not None:
             w.wait()
     torch.cuda.synchronize()
-    # training direction: band forward + band backward, then ONE all-reduce of the flat
-    # parameter-gradient buffer (8 floats per Gaussian)
-    v_image = torch.randn(H, W, 3, device=device)
     t_fb = timed(lambda: (frame.render_band(*inputs),
                           frame.pipe.backward(*inputs, frame.band_grad(v_image))))
     t_fb_ar = timed(lambda: (frame.render_band(*inputs), frame.backward(*inputs, v_image)))
@@ -228,13 +238,20 @@ def bench_tile_row_sharded(device, rank, world, steps=50, warmup=5, workload="uh
         t_to0 = timed(lambda: (frame.render_band(*inputs), frame.gather.gather_to(0)))
     except Exception:  # an exchange this backend cannot do must not cost the other figures
         t_to0 = None
-    return {"workload": f"{workload}: {W}x{H}, {N} Gaussians, tile rows split over {world} ranks",
-            "band_rows": frame.gather.plan, "compute_only_ms": t_compute * 1e3,
-            "compute_plus_allgather_ms": t_total * 1e3,
-            "overlapped_allgather_ms": t_overlap * 1e3,
-            "fps_compute_only": 1.0 / t_compute, "fps_with_allgather": 1.0 / t_total,
-            "fps_overlapped": 1.0 / t_overlap, "scaling": "strong",
-            "compute_plus_gather_to_rank0_ms": None if t_to0 is None else t_to0 * 1e3,
+    ms = lambda t: None if t is None else t * 1e3  # noqa: E731
+    return {"workload": f"{label}: {W}x{H}, {N} Gaussians, tile rows split over {world} ranks",
+            "scaling": "strong", "band_rows": frame.gather.plan,
+            "one_gpu_forward_ms": ms(t_one), "one_gpu_fwd_bwd_ms": ms(t_one_fb),
+            "resident_bands_forward_ms": ms(t_compute),
+            "resident_bands_speedup": t_one / t_compute,
+            "resident_bands_efficiency": t_one / t_compute / world,
+            "forward_plus_allgather_ms": ms(t_total), "allgather_speedup": t_one / t_total,
+            "forward_overlapped_allgather_ms": ms(t_overlap),
+            "overlapped_allgather_speedup": t_one / t_overlap,
+            "forward_plus_gather_to_rank0_ms": ms(t_to0),
             "allgather_bytes_per_rank": frame.gather.slot_rows * W * 3 * 4,
-            "fwd_bwd_compute_only_ms": t_fb * 1e3, "fwd_bwd_plus_allreduce_ms": t_fb_ar * 1e3,
+            "resident_bands_fwd_bwd_ms": ms(t_fb),
+            "resident_bands_fwd_bwd_plus_allreduce_ms": ms(t_fb_ar),
+            "fwd_bwd_allreduce_speedup": t_one_fb / t_fb_ar,
+            "fwd_bwd_allreduce_efficiency": t_one_fb / t_fb_ar / world,
             "allreduce_bytes": 8 * N * 4}

@@ -52,6 +52,9 @@ typedef struct gi2d_conv {
 typedef struct gi2d_workspace gi2d_workspace;
 
 int gi2d_version(void);
+/* Identifies the sources this library was built from (a hash the build script computes over
+ * them): a binding can refuse a library that is older than the sources next to it. */
+const char *gi2d_build_id(void);
 const char *gi2d_error_string(int status);
 void gi2d_default_conv(gi2d_conv *conv);
 
@@ -80,11 +83,29 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
  * next gi2d_fit_forward projects again.  For callers that change the
  * parameters themselves between two iterations. */
 #define GI2D_OPT_DROP_PENDING 3
+/* GI2D_OPT_RECORDS (default 1): the entry points that know colours and opacities when they
+ * project (gi2d_render_*, gi2d_fit_*, gi2d_decode_render) also leave one packed 48-byte record
+ * per Gaussian for the rasteriser, which then gathers one line per list entry instead of four
+ * tensors.  0 = the rasteriser always reads the tensors (same results; used by the tests to
+ * prove that, and by callers that cannot spare 48 bytes per Gaussian). */
+#define GI2D_OPT_RECORDS 5
 /* GI2D_OPT_BWD_SERIAL (testing aid): positions the counter of backward launches, from which
  * the stamps of the backward's partial sums derive (1 .. INT_MAX, then the slots are cleared
  * and the stamps start over), so that a test can cross the wrap. */
 #define GI2D_OPT_BWD_SERIAL 4
 int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value);
+/* Instrumentation: from now on the library records begin_event right before and end_event right
+ * after every launch of one kind of kernel on this workspace (hipEvent_t, created by the caller
+ * with timing enabled), on the stream of the launch; kernel 0 or NULL events switch it off.
+ * A benchmark reads the launch's duration from the pair after synchronising.  Costs two event
+ * records per probed launch and nothing otherwise. */
+#define GI2D_PROBE_PROJECT 1     /* project_*_fwd_kernel (with list filling)           */
+#define GI2D_PROBE_RASTER_FWD 2  /* rasterize_sum_fwd_kernel                            */
+#define GI2D_PROBE_RASTER_BWD 3  /* rasterize_sum_bwd_kernel / _wave_kernel (pass 1)    */
+#define GI2D_PROBE_GATHER 4      /* gather_grads_kernel (pass 2)                        */
+#define GI2D_PROBE_FIT_RASTER 5  /* fit_raster_kernel (forward + loss + backward pass 1) */
+#define GI2D_PROBE_FIT_TAIL 6    /* fit_tail_kernel (gather + chain + Adan + projection) */
+int gi2d_workspace_set_probe(gi2d_workspace *ws, int kernel, void *begin_event, void *end_event);
 /* Tile-row band: binning and rasterisation cover tile rows [row_begin,row_end)
  * of the frame only (row_end is clipped to the frame); out_img / v_out then
  * point at the band's first pixel row.  Default: the whole frame.  This is
@@ -92,9 +113,11 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value);
  * in the single-GPU reference. */
 int gi2d_workspace_set_rows(gi2d_workspace *ws, int row_begin, int row_end);
 /* info[0]=per-tile list capacity, [1]=largest per-tile count published by
- * completed frames, [2]=binning generation, [3]=tiles_x, [4]=tiles_y, [5]=Gaussians binned,
- * [6],[7]=tile rows [begin,end) of the current lists */
-int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[8]);
+ * completed frames, [2]=binning generation, [3]=tiles_x, [4]=tiles_y, [5]=Gaussians binned
+ * (per frame), [6],[7]=tile rows [begin,end) of the current lists, [8]=frames of the current
+ * lists (1 unless gi2d_render_batch made them), [9]=1 if the rasteriser's per-Gaussian records
+ * of the current lists are valid */
+int gi2d_workspace_info(gi2d_workspace *ws, int64_t info[10]);
 
 /* project_gaussians_2d(means2d, L_elements, H, W, tile_bounds)
  * (gaussianimage_cholesky.py:77).  Outputs xys[N,2], depths[N], radii[N],
@@ -203,6 +226,21 @@ typedef struct gi2d_frame_args {
     void *stream;
 } gi2d_frame_args;
 int gi2d_render_frame(const gi2d_frame_args *args);
+
+/* A BATCH of `frames` independent frames of one shape in one call and two launches: frame f
+ * takes Gaussians [f*N, (f+1)*N) of every input tensor ([frames][N][...], contiguous) and
+ * writes its projection outputs to the same rows and its image to out_imgs[f] ([frames][H][W][3]).
+ * The images of a dataset rendered one after the other (the loop over images of
+ * /root/reference/train.py:366-372 and the decode loop of test_quantize.py:71-74 visit one
+ * image at a time) leave most of the chip idle at 768x512; a batch fills it.  Each frame is
+ * bit-identical to the one gi2d_render_frame renders from the same inputs.  Whole frames only
+ * (no tile-row band).  No counterpart in the reference. */
+int gi2d_render_batch(gi2d_workspace *ws, int kind, int frames, const float *means2d,
+                      const float *cov_a, const float *cov_b, const float *colors,
+                      const float *opacity, const float *background, int N, int H, int W,
+                      const gi2d_conv *conv, float *xys, float *depths, int *radii, float *conics,
+                      int *num_tiles_hit, float *out_imgs, void *raster_begin_event,
+                      void *raster_end_event, void *stream);
 
 /* gi2d_render_frame for callers that cannot allocate device memory: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the

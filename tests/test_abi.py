@@ -74,3 +74,10 @@ def test_operators_refuse_cpu_tensors():
     with pytest.raises(ValueError):
         rasterize_gaussians_sum(z(4, 2), z(4), z(4, dtype=torch.int32), z(4, 3),
                                 z(4, dtype=torch.int32), z(4, 3), z(4, 1), 32, 32, 8, 8)
+
+
+def test_library_is_built_from_the_sources_next_to_it():
+    """The build id compiled into the library is the hash of the sources on disk (a stale
+    library is refused at import, which this test would not even reach)."""
+    from gaussianimage_amd import _lib, build
+    assert _lib.lib.gi2d_build_id().decode() == build.source_id()

@@ -48,7 +48,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 24 and d["warmup"] == 3 and d["vs_baseline"] is None
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f32"
-    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6
+    # one step renders one batch of frames: value [frames/s] x ms_per_step = frames per step
+    B = d["config"]["frames_per_step"]
+    assert B >= 1 and abs(d["value"] * d["ms_per_step"] * 1e-3 - B) < 1e-6 * B
+    assert d["timed_regions"] >= 3 and d["frames_timed"] == d["timed_regions"] * 24 * B
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
@@ -56,3 +59,4 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert r["bytes_with_lists_held"] <= r["algorithmic_bytes_per_launch"]

@@ -448,14 +448,16 @@ def test_asynchronous_overflow_is_loud_and_repaired(ops, oracle):
     opa = torch.ones(N, 1, device=DEV)
     z = torch.zeros(N, device=DEV)
     nth = torch.zeros(N, dtype=torch.int32, device=DEV)
-    # a fresh workspace: the shared one has grown in earlier tests and never shrinks
-    idx = torch.device(DEV).index or 0
-    saved = ops._WORKSPACES.get(idx)
-    ops._WORKSPACES[idx] = ops.Workspace(DEV)
+    # a fresh workspace: the shared one has grown in earlier tests and never shrinks; strict, so
+    # that the report of the earlier frame's overflow comes as the exception it is underneath
+    key = (torch.device(DEV).index or 0, 0)
+    saved = ops._WORKSPACES.get(key)
+    ops._WORKSPACES[key] = ops.Workspace(DEV)
+    ops._WORKSPACES[key].strict = True
     try:
         _overflow_scenario(ops, oracle, xys, small, big, conics, col, opa, z, nth, H, W)
     finally:
-        ops._WORKSPACES[idx] = saved
+        ops._WORKSPACES[key] = saved
 
 
 def _overflow_scenario(ops, oracle, xys, small, big, conics, col, opa, z, nth, H, W):
@@ -1143,3 +1145,91 @@ def test_backward_stamps_wrap_without_stale_sums(ops, oracle):
         got = [g for g in pipe.backward(*a, v_img) if g is not None]
         for g, w in zip(got, want_low if k % 2 else want):
             assert torch.equal(g, w), k
+
+
+def test_two_streams_through_the_operators_do_not_share_lists(ops, oracle):
+    """Two frames on two streams, their projection / rasterisation / backward calls interleaved
+    from one host thread: every stream has its own operator workspace, so each frame gets the
+    image and gradients it gets alone on the default stream."""
+    H, W = 96, 128
+    tb = oracle.tile_bounds(H, W)
+    frames = []
+    for seed, N, fp in ((21, 2500, 2.0), (22, 1200, 1.0)):
+        means, L, col, op = synth.cholesky_inputs(N, seed=seed, footprint=fp)
+        v = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(seed))
+        frames.append([t.to(DEV) for t in (means, L, col, op, v)])
+
+    def leaves(f):
+        return [t.clone().requires_grad_(True) for t in f[:3]]
+
+    # alone, one after the other, on the default stream
+    want = []
+    for f in frames:
+        m, l, c = leaves(f)
+        img = ops.rasterize_gaussians_sum(*ops.project_gaussians_2d(m, l, H, W, tb), c, f[3], H, W,
+                                          16, 16)
+        (img * f[4]).sum().backward()
+        want.append([img.detach().clone(), m.grad.clone(), l.grad.clone(), c.grad.clone()])
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    assert ops.get_workspace(DEV) is ops.get_workspace(DEV)
+    with torch.cuda.stream(streams[0]):
+        ws0 = ops.get_workspace(DEV)
+    with torch.cuda.stream(streams[1]):
+        assert ops.get_workspace(DEV) is not ws0
+    lv = [leaves(f) for f in frames]
+    proj, imgs = [None, None], [None, None]
+    for rep in range(3):
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                proj[k] = ops.project_gaussians_2d(lv[k][0], lv[k][1], H, W, tb)
+        for k in (1, 0):
+            with torch.cuda.stream(streams[k]):
+                imgs[k] = ops.rasterize_gaussians_sum(*proj[k], lv[k][2], frames[k][3], H, W, 16, 16)
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                for t in lv[k]:
+                    t.grad = None
+                (imgs[k] * frames[k][4]).sum().backward()
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        got = [imgs[k].detach(), lv[k][0].grad, lv[k][1].grad, lv[k][2].grad]
+        for g, w in zip(got, want[k]):
+            assert torch.equal(g, w), k
+
+
+def test_late_overflow_report_does_not_stop_the_operators(ops, oracle):
+    """The operators swallow the report of an EARLIER frame's overflow (count it, warn once);
+    strict=True brings the exception back."""
+    import warnings
+    from gaussianimage_amd import _lib
+    H, W, N = 64, 64, 1500
+    tb = oracle.tile_bounds(H, W)
+    z = torch.zeros(N, device=DEV)
+    nth = torch.zeros(N, dtype=torch.int32, device=DEV)
+    col, opa = torch.rand(N, 3, device=DEV), torch.ones(N, 1, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    xys = (torch.rand(N, 2, generator=g) * torch.tensor([W, H])).to(DEV)
+    conics = torch.tensor([[0.5, 0.0, 0.5]]).repeat(N, 1).to(DEV)
+    small = torch.full((N,), 2, dtype=torch.int32, device=DEV)
+    big = torch.full((N,), 60, dtype=torch.int32, device=DEV)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):     # a stream of its own: a fresh workspace
+        ws = ops.get_workspace(DEV)
+        for _ in range(3):
+            ops.rasterize_gaussians_sum(xys.clone(), z, small, conics, nth, col, opa, H, W, 16, 16)
+        torch.cuda.synchronize()
+        img = ops.rasterize_gaussians_sum(xys.clone(), z, big, conics, nth, col, opa, H, W, 16, 16)
+        torch.cuda.synchronize()
+        assert torch.isnan(img).any()          # that frame's overflowed tiles are marked
+        before = ws.late_overflows
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            # (the report travels device -> pinned host memory with the NEXT launch: it reaches
+            # the host one or two calls after the frame it is about)
+            for _ in range(3):
+                img = ops.rasterize_gaussians_sum(xys.clone(), z, big, conics, nth, col, opa, H,
+                                                  W, 16, 16)
+                torch.cuda.synchronize()
+        assert 1 <= ws.late_overflows - before <= 2 and torch.isfinite(img).all()
+        assert any("overflowed a tile list" in str(w.message) for w in caught)
