@@ -27,15 +27,21 @@ struct ChainArgs {
     long long generation;
 };
 
+// Per-Gaussian gradients of the rasteriser handed in from outside (GRADS = true): the sums a
+// tile-row sharded fit has reduced over its ranks, in place of this workspace's partial sums.
+struct GradIn {
+    const float *v_xy, *v_conic, *v_colors;  // [N,2], [N,3], [N,3]
+};
+
 // CHAIN = true: having updated Gaussian g's parameters, the lane goes straight on to the next
 // iteration's projection of g (model activations included) -- outputs overwritten in place,
 // tile lists of the next frame filled -- so the next iteration needs no projection launch.
-template <bool RS, bool CHAIN>
+template <bool RS, bool CHAIN, bool GRADS>
 __global__ __launch_bounds__(256) void fit_tail_kernel(
     AdanTensors T, AdanScalars h, float *xys, int *radii, int N, int H, int W, int tiles_x,
     int tiles_y, int row0, int row1, const int *__restrict__ tile_len,
     const int *__restrict__ seg, int C, const float *__restrict__ partials,
-    const float *__restrict__ gslots, size_t gslot_n, int stamp, ChainArgs ch)
+    const float *__restrict__ gslots, size_t gslot_n, int stamp, ChainArgs ch, GradIn gin)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (CHAIN && g == 0) publish_status(ch.status, ch.h_status, ch.generation);
@@ -49,8 +55,20 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
     const AdanSlot f0 = adan_load(T, 3, g3), f1 = adan_load(T, 3, g3 + 1),
                    f2 = adan_load(T, 3, g3 + 2);
     float acc[PART_STRIDE];
-    gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
-                    tile_len, seg, C, partials, gslots, gslot_n, stamp, acc);
+    if (GRADS) {
+        acc[0] = gin.v_xy[g2];
+        acc[1] = gin.v_xy[g2 + 1];
+        acc[2] = gin.v_conic[g3];
+        acc[3] = gin.v_conic[g3 + 1];
+        acc[4] = gin.v_conic[g3 + 2];
+        acc[5] = gin.v_colors[g3];
+        acc[6] = gin.v_colors[g3 + 1];
+        acc[7] = gin.v_colors[g3 + 2];
+        acc[8] = 0.f;
+    } else {
+        gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
+                        tile_len, seg, C, partials, gslots, gslot_n, stamp, acc);
+    }
     const float t0 = tanhf(x0.p), t1 = tanhf(x1.p);
     // means = tanh(_xyz); xys = 0.5*(W,H)*means + ...
     const float gx0 = 0.5f * (float)W * acc[0] * (1.0f - t0 * t0);
@@ -256,6 +274,30 @@ fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *
                    stamp);
 }
 
+// Pass 2 on its own (gi2d_fit_raster): every Gaussian's partial sums of THIS workspace's tiles.
+__global__ __launch_bounds__(256) void gather_grads_kernel_fit(
+    const float *__restrict__ xys, const int *__restrict__ radii, int N, int tiles_x, int tiles_y,
+    int row0, int row1, const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
+    const float *__restrict__ partials, const float *__restrict__ gslots, size_t gslot_n,
+    int stamp, float *__restrict__ v_xy, float *__restrict__ v_conic,
+    float *__restrict__ v_colors, float *__restrict__ v_opacity)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float acc[PART_STRIDE];
+    gather_partials(g, radii[g], xys[2 * g], xys[2 * g + 1], tiles_x, tiles_y, row0, row1,
+                    tile_len, seg, C, partials, gslots, gslot_n, stamp, acc);
+    v_xy[2 * g] = acc[0];
+    v_xy[2 * g + 1] = acc[1];
+    v_conic[3 * g] = acc[2];
+    v_conic[3 * g + 1] = acc[3];
+    v_conic[3 * g + 2] = acc[4];
+    v_colors[3 * g] = acc[5];
+    v_colors[3 * g + 1] = acc[6];
+    v_colors[3 * g + 2] = acc[7];
+    v_opacity[g] = acc[8];
+}
+
 __global__ __launch_bounds__(256) void adan_step_kernel(AdanTensors T, AdanScalars h,
                                                         const float *__restrict__ clip_dev)
 {
@@ -363,7 +405,8 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
                              const float *conics, const float *v_image, float *const *exp_avg,
                              float *const *exp_avg_sq, float *const *exp_avg_diff,
                              float *const *neg_pre_grad, const gi2d_adan_hyper *hyper,
-                             void *stream, const ChainOutputs *chain, bool pass1_done = false)
+                             void *stream, const ChainOutputs *chain, bool pass1_done = false,
+                             const GradIn *grads = nullptr)
 {
     if (kind != 0 && kind != 1) return GI2D_E_INVALID;
     int rc = check_raster_args(ws, N, H, W, conv);
@@ -418,22 +461,29 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
         ch.h_status = ws->h_status_dev;
         ch.generation = ws->generation;
     }
+    const GradIn gin = grads ? *grads : GradIn{nullptr, nullptr, nullptr};
     // (the kernel reads xys / radii of the current frame and, chained, overwrites them)
     float *xys_io = chained ? chain->xys : const_cast<float *>(xys);
     int *radii_io = chained ? chain->radii : const_cast<int *>(radii);
 #define GI2D_TAIL_ARGS Tn, h, xys_io, radii_io, N, H, W, ws->tiles_x, ws->tiles_y, ws->bin_row0, \
                        ws->bin_row1, ws->d_len, ws->d_seg, ws->seg_cap, ws->d_partials,          \
-                       ws->d_gslots, (size_t)ws->slot_cap, ws->bwd_stamp, ch
+                       ws->d_gslots, (size_t)ws->slot_cap, ws->bwd_stamp, ch, gin
     // one wave per workgroup when the lanes also issue the list-filling atomics, so that the
     // launch spreads over every CU (as in the projection kernels)
     const int threads = chained ? PG_THREADS : 256;
     const dim3 grid(cdiv(N, threads)), block(threads);
     {
     Probe probe(ws, GI2D_PROBE_FIT_TAIL, st);
-    if (kind == 0 && chained) fit_tail_kernel<false, true><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
-    else if (kind == 0) fit_tail_kernel<false, false><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
-    else if (chained) fit_tail_kernel<true, true><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
-    else fit_tail_kernel<true, false><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);
+#define GI2D_TAIL(RS, GR)                                                                   \
+    do {                                                                                    \
+        if (chained) fit_tail_kernel<RS, true, GR><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);  \
+        else fit_tail_kernel<RS, false, GR><<<grid, block, 0, st>>>(GI2D_TAIL_ARGS);         \
+    } while (0)
+    if (kind == 0 && grads) GI2D_TAIL(false, true);
+    else if (kind == 0) GI2D_TAIL(false, false);
+    else if (grads) GI2D_TAIL(true, true);
+    else GI2D_TAIL(true, false);
+#undef GI2D_TAIL
     }
 #undef GI2D_TAIL_ARGS
     rc = launch_status();
@@ -476,30 +526,31 @@ int gi2d_fit_backward_step_chain(gi2d_workspace *ws, int kind, float *xyz, float
                              neg_pre_grad, hyper, stream, &chain);
 }
 
-int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
-                  float *features, const float *opacity, const float *background,
-                  const float *gt_chw, int N, int H, int W, const gi2d_conv *conv, float *xys,
-                  float *depths, int *radii, float *conics, int *num_tiles_hit, float *image,
-                  float *loss_partials, float *const *exp_avg, float *const *exp_avg_sq,
-                  float *const *exp_avg_diff, float *const *neg_pre_grad,
-                  const gi2d_adan_hyper *hyper, void *stream)
+// Projection (unless a chained tail prepared it), binning bookkeeping and the fused rasterisation
+// kernel (forward, loss, backward pass 1) of one fitting iteration.
+static int fit_raster_impl(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
+                           const float *cov_b, const float *features, const float *opacity,
+                           const float *background, const float *gt_chw, int N, int H, int W,
+                           const gi2d_conv *conv, float *xys, float *depths, int *radii,
+                           float *conics, int *num_tiles_hit, float *image, float *loss_partials,
+                           void *stream, int *late_out, bool *ran)
 {
-    if (!ws || (kind != 0 && kind != 1) || !gt_chw || !loss_partials || !hyper || hyper->step < 1)
-        return GI2D_E_INVALID;
+    *ran = false;
+    if (!ws || (kind != 0 && kind != 1) || !gt_chw || !loss_partials) return GI2D_E_INVALID;
     if (N > 0 && (!xys || !depths || !radii || !conics || !num_tiles_hit)) return GI2D_E_INVALID;
     if (N > 0 && (!xyz || !cov_a || (kind == 1 && !cov_b) || !features || !opacity))
         return GI2D_E_INVALID;
     if (conv && conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
-    int rc = fit_project_bin(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys, depths,
-                             radii, conics, num_tiles_hit, stream);
+    int rc = fit_project_bin(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
+                             depths, radii, conics, num_tiles_hit, stream);
     if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
-    const int late = rc;
+    *late_out = rc;
     rc = check_raster_args(ws, N, H, W, conv);
     if (rc != GI2D_OK) return rc;
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (T == 0) {  // empty band
         ws->lists_raw = false;
-        return late;
+        return GI2D_OK;
     }
     DeviceGuard guard(ws->device);
     hipStream_t st = (hipStream_t)stream;
@@ -536,13 +587,81 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
     }
 #undef GI2D_FIT_RASTER
 #undef GI2D_FIT_RASTER_ARGS
-    rc = launch_status();
+    *ran = true;
+    return launch_status();
+}
+
+int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                  float *features, const float *opacity, const float *background,
+                  const float *gt_chw, int N, int H, int W, const gi2d_conv *conv, float *xys,
+                  float *depths, int *radii, float *conics, int *num_tiles_hit, float *image,
+                  float *loss_partials, float *const *exp_avg, float *const *exp_avg_sq,
+                  float *const *exp_avg_diff, float *const *neg_pre_grad,
+                  const gi2d_adan_hyper *hyper, void *stream)
+{
+    if (!hyper || hyper->step < 1) return GI2D_E_INVALID;
+    int late = GI2D_OK;
+    bool ran = false;
+    int rc = fit_raster_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, background, gt_chw, N,
+                             H, W, conv, xys, depths, radii, conics, num_tiles_hit, image,
+                             loss_partials, stream, &late, &ran);
     if (rc != GI2D_OK) return rc;
+    if (!ran) return late;  // empty band
     const ChainOutputs chain = {xys, depths, conics, radii, num_tiles_hit};
     rc = fit_backward_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
                            radii, conics, nullptr, exp_avg, exp_avg_sq, exp_avg_diff, neg_pre_grad,
                            hyper, stream, &chain, true);
     return rc != GI2D_OK ? rc : late;
+}
+
+int gi2d_fit_raster(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
+                    const float *cov_b, const float *features, const float *opacity,
+                    const float *background, const float *gt_chw, int N, int H, int W,
+                    const gi2d_conv *conv, float *xys, float *depths, int *radii, float *conics,
+                    int *num_tiles_hit, float *image, float *loss_partials, float *v_xys,
+                    float *v_conics, float *v_colors, float *v_opacity, void *stream)
+{
+    if (N > 0 && (!v_xys || !v_conics || !v_colors || !v_opacity)) return GI2D_E_INVALID;
+    int late = GI2D_OK;
+    bool ran = false;
+    int rc = fit_raster_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, background, gt_chw, N,
+                             H, W, conv, xys, depths, radii, conics, num_tiles_hit, image,
+                             loss_partials, stream, &late, &ran);
+    if (rc != GI2D_OK) return rc;
+    if (N == 0) return late;
+    DeviceGuard guard(ws->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (!ran) {  // an empty band contributes zeros
+        rc = ensure_bwd_buffers(ws, N);
+        if (rc == GI2D_OK) rc = next_bwd_stamp(ws, st);
+        if (rc != GI2D_OK) return rc;
+    }
+    {
+        Probe probe(ws, GI2D_PROBE_GATHER, st);
+        gather_grads_kernel_fit<<<cdiv(N, 256), 256, 0, st>>>(
+            xys, radii, N, ws->tiles_x, ws->tiles_y, ws->bin_row0, ws->bin_row1, ws->d_len,
+            ws->d_seg, ws->seg_cap, ws->d_partials, ws->d_gslots, (size_t)ws->slot_cap,
+            ws->bwd_stamp, v_xys, v_conics, v_colors, v_opacity);
+    }
+    rc = launch_status();
+    return rc != GI2D_OK ? rc : late;
+}
+
+int gi2d_fit_tail(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                  float *features, const float *opacity, int N, int H, int W,
+                  const gi2d_conv *conv, float *xys, float *depths, int *radii, float *conics,
+                  int *num_tiles_hit, const float *v_xys, const float *v_conics,
+                  const float *v_colors, float *const *exp_avg, float *const *exp_avg_sq,
+                  float *const *exp_avg_diff, float *const *neg_pre_grad,
+                  const gi2d_adan_hyper *hyper, void *stream)
+{
+    if (!xys || !depths || !radii || !conics || !num_tiles_hit) return GI2D_E_INVALID;
+    if (N > 0 && (!v_xys || !v_conics || !v_colors)) return GI2D_E_INVALID;
+    const ChainOutputs chain = {xys, depths, conics, radii, num_tiles_hit};
+    const GradIn gin = {v_xys, v_conics, v_colors};
+    return fit_backward_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
+                             radii, conics, nullptr, exp_avg, exp_avg_sq, exp_avg_diff,
+                             neg_pre_grad, hyper, stream, &chain, true, &gin);
 }
 
 int gi2d_adan_step(int num_tensors, float *const *params, float *const *grads,

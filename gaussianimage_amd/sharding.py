@@ -21,8 +21,8 @@ import torch.distributed as dist
 
 from ._lib import BLOCK
 
-__all__ = ["band_plan", "band_pixels", "BandGather", "all_reduce_grads", "ShardedFrame",
-           "bench_tile_row_sharded"]
+__all__ = ["band_plan", "band_pixels", "BandGather", "all_reduce_grads", "GradExchange",
+           "ShardedFrame", "ShardedFitter", "bench_tile_row_sharded"]
 
 
 def band_plan(tiles_y, world_size):
@@ -173,6 +173,116 @@ class ShardedFrame:
         return grads
 
 
+class GradExchange:
+    """The one exchange of a tile-row sharded fitting step: every rank's per-Gaussian partial
+    gradients of the rasteriser -- v_xys[N,2], v_conics[N,3], v_colors[N,3], v_opacity[N], views
+    of ONE flat buffer of 9 N floats -- are summed over the ranks by a single all-reduce (RCCL
+    when the backend is ``nccl``; a ``gloo`` group gets the buffer through host memory)."""
+
+    def __init__(self, num_points, device, group=None):
+        N = int(num_points)
+        self.group = group
+        self.flat = torch.zeros(9 * N, dtype=torch.float32, device=device)
+        self.v_xys = self.flat[: 2 * N].view(N, 2)
+        self.v_conics = self.flat[2 * N: 5 * N].view(N, 3)
+        self.v_colors = self.flat[5 * N: 8 * N].view(N, 3)
+        self.v_opacity = self.flat[8 * N:]
+
+    def reduce(self):
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        if _backend(self.group) == "gloo" and self.flat.is_cuda:
+            buf = self.flat.cpu()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.copy_(buf)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+
+class ShardedFitter:
+    """The fused fitting loop with the image split by tile rows over the ranks.
+
+    Every rank holds ALL parameters and the whole optimizer state (8 floats per Gaussian and
+    their moments: a few MB) and the whole target image, and rasterises only its band of tile
+    rows.  One iteration is ``gi2d_fit_raster`` on the band (projection, forward, L2 loss,
+    backward partial sums, their sum per Gaussian) -> ONE all-reduce of 9 N floats ->
+    ``gi2d_fit_tail`` (chain rule, Adan, and the projection of the updated parameters into the
+    band's next lists): three launches and one collective, and because every rank applies the
+    same update to the same parameters, the replicas never drift apart.  With one rank it gives
+    the bits of ``FusedFitter``.  The reference fits on one GPU
+    (/root/reference/gaussianimage_cholesky.py:101-124); this has no counterpart there."""
+
+    def __init__(self, num_points, H, W, kind, rank, world_size, device, group=None, rows=None,
+                 **fitter_args):
+        import ctypes
+        from . import _lib
+        from ._lib import lib
+        from .fit import FusedFitter
+        self._ctypes, self._lib, self._clib = ctypes, _lib, lib
+        self.rank, self.world, self.group = rank, world_size, group
+        self.H, self.W = int(H), int(W)
+        tiles_y = (self.H + BLOCK - 1) // BLOCK
+        self.plan = band_plan(tiles_y, world_size)
+        self.rows = self.plan[rank] if rows is None else rows
+        self.fit = FusedFitter(num_points, H, W, kind=kind, device=device, keep_image=False,
+                               **fitter_args)
+        self.fit.ws.set_rows(*self.rows)
+        tiles_x = (self.W + BLOCK - 1) // BLOCK
+        # (one loss partial per tile of the band; the full-frame buffer is large enough)
+        self.band_tiles = tiles_x * (self.rows[1] - self.rows[0])
+        self.exchange = GradExchange(num_points, self.fit.device, group)
+        self._bind()
+
+    def _bind(self):
+        from .ops import _ptr
+        f, x = self.fit, self.exchange
+        p = [f.params[k] if k else None for k in f.names]
+        self._raster_args = (f.ws.handle, f._kind, _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(p[3]),
+                             _ptr(f._opacity), _ptr(f.background))
+        self._raster_tail = (f.N, f.H, f.W, self._ctypes.byref(f.conv), _ptr(f.xys),
+                             _ptr(f.depths), _ptr(f.radii), _ptr(f.conics), _ptr(f.num_tiles_hit),
+                             None, _ptr(f.loss_partials), _ptr(x.v_xys), _ptr(x.v_conics),
+                             _ptr(x.v_colors), _ptr(x.v_opacity))
+        self._tail_args = (f.ws.handle, f._kind, _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(p[3]),
+                           _ptr(f._opacity), f.N, f.H, f.W, self._ctypes.byref(f.conv),
+                           _ptr(f.xys), _ptr(f.depths), _ptr(f.radii), _ptr(f.conics),
+                           _ptr(f.num_tiles_hit), _ptr(x.v_xys), _ptr(x.v_conics),
+                           _ptr(x.v_colors), *f._state_arrays)
+
+    def step(self, gt_image):
+        """One fitting iteration; ``gt_image`` is the whole [1,3,H,W] target on every rank."""
+        from .ops import _ptr
+        f, lib, _lib = self.fit, self._clib, self._lib
+        f._check_target(gt_image)
+        if f.ws.rows != self.rows:
+            f.ws.set_rows(*self.rows)
+        lr = f.lr
+        rc = lib.gi2d_fit_raster(*self._raster_args, _ptr(gt_image), *self._raster_tail, f._stream)
+        _lib.check(f._late_overflow(rc), "gi2d_fit_raster")
+        self.exchange.reduce()
+        f.step_count += 1
+        b1, b2, b3 = f.betas
+        hyper = _lib.AdanHyper(lr, b1, b2, b3, f.eps, f.weight_decay, int(bool(f.no_prox)),
+                               f.step_count)
+        rc = lib.gi2d_fit_tail(*self._tail_args, self._ctypes.byref(hyper), f._stream)
+        f._versions = f._param_versions()
+        _lib.check(rc, "gi2d_fit_tail")
+
+    def loss(self):
+        """Mean squared error of the last forward over the WHOLE frame (sums the bands' partial
+        sums over the ranks; synchronises)."""
+        part = self.fit.loss_partials[: self.band_tiles].double().sum().reshape(1)
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            buf = part.cpu() if _backend(self.group) == "gloo" else part
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            part = buf
+        return float(part.item()) / (3 * self.H * self.W)
+
+    @property
+    def params(self):
+        return self.fit.params
+
+
 def bench_tile_row_sharded(device, rank, world, shape, inputs, steps=50, warmup=5, label=""):
     """Times one frame of ``shape = (H, W, N, kind)`` split by tile rows over ``world`` ranks
     (``inputs``: the replicated operator inputs on ``device``), max over ranks:
@@ -238,6 +348,19 @@ def bench_tile_row_sharded(device, rank, world, shape, inputs, steps=50, warmup=
         t_to0 = timed(lambda: (frame.render_band(*inputs), frame.gather.gather_to(0)))
     except Exception:  # an exchange this backend cannot do must not cost the other figures
         t_to0 = None
+    # the fused fitting step: whole frame on one GPU (two launches) against the sharded step
+    # (band rasterisation, one all-reduce of 9 N floats, tail: three launches + one collective)
+    from ._testing import synth
+    from .fit import FusedFitter
+    gt = synth.target_image(H, W).to(device)
+    torch.manual_seed(1)
+    one = FusedFitter(N, H, W, kind=kind, device=device, keep_image=False)
+    t_fit_one = timed(lambda: one.step(gt))
+    del one
+    torch.manual_seed(1)
+    many = ShardedFitter(N, H, W, kind, rank, world, device)
+    t_fit_many = timed(lambda: many.step(gt))
+    del many
     ms = lambda t: None if t is None else t * 1e3  # noqa: E731
     return {"workload": f"{label}: {W}x{H}, {N} Gaussians, tile rows split over {world} ranks",
             "scaling": "strong", "band_rows": frame.gather.plan,
@@ -254,4 +377,8 @@ def bench_tile_row_sharded(device, rank, world, shape, inputs, steps=50, warmup=
             "resident_bands_fwd_bwd_plus_allreduce_ms": ms(t_fb_ar),
             "fwd_bwd_allreduce_speedup": t_one_fb / t_fb_ar,
             "fwd_bwd_allreduce_efficiency": t_one_fb / t_fb_ar / world,
-            "allreduce_bytes": 8 * N * 4}
+            "allreduce_bytes": 8 * N * 4,
+            "one_gpu_fused_fit_step_ms": ms(t_fit_one), "sharded_fit_step_ms": ms(t_fit_many),
+            "sharded_fit_speedup": t_fit_one / t_fit_many,
+            "sharded_fit_efficiency": t_fit_one / t_fit_many / world,
+            "sharded_fit_allreduce_bytes": 9 * N * 4}

@@ -346,6 +346,34 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
                   float *const *exp_avg_diff, float *const *neg_pre_grad,
                   const gi2d_adan_hyper *hyper, void *stream);
 
+/* gi2d_fit_step split where a tile-row sharded fit exchanges gradients (every rank holds all
+ * parameters and the optimizer state, and rasterises its own band of tile rows, see
+ * gi2d_workspace_set_rows):
+ *   gi2d_fit_raster -- projection (unless the previous tail prepared it), binning, the fused
+ *       rasterisation kernel on the workspace's tile rows, and the sum of every Gaussian's
+ *       partial sums over THESE rows: v_xys[N,2], v_conics[N,3], v_colors[N,3], v_opacity[N].
+ *       gt_chw is the whole [3,H,W] target (only the band's rows are read); image, if given,
+ *       is the band; loss_partials has one entry per tile of the band.
+ *   (the caller adds the four tensors over the ranks: one all-reduce of 9 N floats)
+ *   gi2d_fit_tail -- per Gaussian the chain through projection and activations, the Adan
+ *       update in place and the projection of the updated parameters for the next iteration,
+ *       from the reduced v_xys / v_conics / v_colors.
+ * With one rank (the whole frame) the two calls give the bits of gi2d_fit_step.  No counterpart
+ * in the reference, which is single-GPU (gaussianimage_cholesky.py:116-123 is the step split). */
+int gi2d_fit_raster(gi2d_workspace *ws, int kind, const float *xyz, const float *cov_a,
+                    const float *cov_b, const float *features, const float *opacity,
+                    const float *background, const float *gt_chw, int N, int H, int W,
+                    const gi2d_conv *conv, float *xys, float *depths, int *radii, float *conics,
+                    int *num_tiles_hit, float *image, float *loss_partials, float *v_xys,
+                    float *v_conics, float *v_colors, float *v_opacity, void *stream);
+int gi2d_fit_tail(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float *cov_b,
+                  float *features, const float *opacity, int N, int H, int W,
+                  const gi2d_conv *conv, float *xys, float *depths, int *radii, float *conics,
+                  int *num_tiles_hit, const float *v_xys, const float *v_conics,
+                  const float *v_colors, float *const *exp_avg, float *const *exp_avg_sq,
+                  float *const *exp_avg_diff, float *const *neg_pre_grad,
+                  const gi2d_adan_hyper *hyper, void *stream);
+
 /* ---- codec decode path ------------------------------------------------------
  * The coded attributes of one image, as compress_wo_ec() leaves them
  * (gaussianimage_cholesky.py:154-159, gaussianimage_rs.py:125-130) together

@@ -250,3 +250,83 @@ def test_fitter_on_degenerate_sizes(N, H, W):
     if N == 0:
         want = float((gt.clamp(0, 1) ** 2).mean())   # an empty model renders black
         assert abs(a.loss() - want) <= 1e-6 * max(want, 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cholesky", "rs"])
+def test_split_step_with_one_band_is_the_fused_step(kind):
+    """gi2d_fit_raster + gi2d_fit_tail over the whole frame (the tile-row sharded step with one
+    rank, no exchange) leave the bits of gi2d_fit_step."""
+    from gaussianimage_amd.fit import FusedFitter
+    from gaussianimage_amd.sharding import ShardedFitter
+    H, W, N = 96, 112, 2500
+    gt = synth.target_image(H, W).to(DEV)
+    torch.manual_seed(11)
+    a = FusedFitter(N, H, W, kind=kind, device=DEV, keep_image=False)
+    torch.manual_seed(11)
+    b = ShardedFitter(N, H, W, kind, 0, 1, DEV)
+    for it in range(7):
+        a.step(gt)
+        b.step(gt)
+        assert a.loss() == b.loss(), it
+    for k in a.params:
+        assert torch.equal(a.params[k], b.params[k]), k
+        for s in a.state[k]:
+            assert torch.equal(a.state[k][s], b.fit.state[k][s]), (k, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world", [("cholesky", 2), ("cholesky", 3), ("rs", 4)])
+def test_sharded_fit_on_one_device_follows_the_unsharded_fit(kind, world):
+    """Tile-row sharded fitting emulated on one device: `world` fitters, each with its band,
+    exchange their per-Gaussian partial gradients by a plain sum (what the all-reduce does) and
+    apply the same update.  The replicas stay bit-identical to each other, and follow the
+    unsharded fused fit up to the re-association of the per-band sums."""
+    from gaussianimage_amd.fit import FusedFitter
+    from gaussianimage_amd.sharding import ShardedFitter
+    H, W, N = 120, 112, 3000     # 8 tile rows: uneven bands for world = 3
+    gt = synth.target_image(H, W).to(DEV)
+    torch.manual_seed(12)
+    ref = FusedFitter(N, H, W, kind=kind, device=DEV, keep_image=False)
+    ranks = []
+    for r in range(world):
+        torch.manual_seed(12)
+        ranks.append(ShardedFitter(N, H, W, kind, r, world, DEV))
+    assert sorted(x for f in ranks for x in range(*f.rows)) == list(range((H + 15) // 16))
+
+    class SumOverRanks:      # stands in for the process group's all-reduce
+        def __init__(self):
+            self.pending = []
+
+        def reduce_all(self):
+            total = torch.stack([f.exchange.flat for f in ranks]).sum(0)
+            for f in ranks:
+                f.exchange.flat.copy_(total)
+
+    from gaussianimage_amd import _lib
+    from gaussianimage_amd.ops import _ptr
+    import ctypes
+    for it in range(8):
+        ref.step(gt)
+        # the three phases of ShardedFitter.step, rank by rank, with the sum in between
+        for f in ranks:
+            f.fit._check_target(gt)
+            rc = _lib.lib.gi2d_fit_raster(*f._raster_args, _ptr(gt), *f._raster_tail, f.fit._stream)
+            _lib.check(f.fit._late_overflow(rc), "gi2d_fit_raster")
+        SumOverRanks().reduce_all()
+        for f in ranks:
+            ff = f.fit
+            lr = ff.lr
+            ff.step_count += 1
+            b1, b2, b3 = ff.betas
+            hyper = _lib.AdanHyper(lr, b1, b2, b3, ff.eps, ff.weight_decay, 0, ff.step_count)
+            _lib.check(_lib.lib.gi2d_fit_tail(*f._tail_args, ctypes.byref(hyper), ff._stream),
+                       "gi2d_fit_tail")
+            ff._versions = ff._param_versions()
+        loss = sum(float(f.fit.loss_partials[: f.band_tiles].double().sum()) for f in ranks) / (
+            3 * H * W)
+        assert abs(loss - ref.loss()) <= 1e-6 * max(ref.loss(), 1e-12), it
+    for k in ref.params:
+        for f in ranks[1:]:
+            assert torch.equal(f.params[k], ranks[0].params[k]), k
+        assert _maxrel(ranks[0].params[k], ref.params[k]) <= 2e-5, k
