@@ -231,12 +231,29 @@ __device__ __forceinline__ int fwd_tile(
             else chunk(std::true_type());
         }
     }
-    // the background is read on the device (three uniform loads) and only when it counts
+    // The background is read on the device (three uniform loads) and added only when it counts;
+    // an overflowed segment turns the tile's pixels into NaN (never silently wrong).  Both are
+    // uniform over the workgroup and rare: real branches, nothing on the usual path.
     float bg[3] = {0.f, 0.f, 0.f};
     if (cv.bg_weight != 0.f) {
-        bg[0] = background[0];
-        bg[1] = background[1];
-        bg[2] = background[2];
+        bg[0] = cv.bg_weight * background[0];
+        bg[1] = cv.bg_weight * background[1];
+        bg[2] = cv.bg_weight * background[2];
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) {
+            r[u] += bg[0];
+            g[u] += bg[1];
+            b[u] += bg[2];
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) xacc[q] += bg[q % 3];
+    }
+    if (n_raw > C) {
+        const float nan = __builtin_nanf("");
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) r[u] = g[u] = b[u] = nan;
+#pragma unroll
+        for (int q = 0; q < NX; ++q) xacc[q] = nan;
     }
     float sq[PPL];
     float keep_vo[PPL][3];  // (pixels outside the image keep a zero gradient)
@@ -244,10 +261,7 @@ __device__ __forceinline__ int fwd_tile(
     for (int u = 0; u < PPL; ++u) keep_vo[u][0] = keep_vo[u][1] = keep_vo[u][2] = 0.f;
 #pragma unroll
     for (int u = 0; u < PPL; ++u) {
-        float rr = r[u] + cv.bg_weight * bg[0];
-        float gg = g[u] + cv.bg_weight * bg[1];
-        float bb = b[u] + cv.bg_weight * bg[2];
-        if (n_raw > C) rr = gg = bb = __builtin_nanf("");  // overflowed segment: never silently wrong
+        const float rr = r[u], gg = g[u], bb = b[u];
         if (inside[u] && out != nullptr) {
             float *o = out + 3 * pix[u];
             o[0] = rr;
@@ -288,13 +302,8 @@ __device__ __forceinline__ int fwd_tile(
         }
     }
     if (NX && inside[0]) {
-        const float *bgs = bg;
 #pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            float v = xacc[q] + cv.bg_weight * bgs[q % 3];
-            if (n_raw > C) v = __builtin_nanf("");
-            extra.out[q / 3][3 * pix[0] + q % 3] = v;
-        }
+        for (int q = 0; q < NX; ++q) extra.out[q / 3][3 * pix[0] + q % 3] = xacc[q];
     }
     if (KEEP) {
 #pragma unroll
