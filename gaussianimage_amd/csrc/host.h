@@ -42,6 +42,7 @@ struct gi2d_workspace {
     // instrumentation (gi2d_workspace_set_probe): events recorded around one kind of launch
     int probe_kernel = 0;
     hipEvent_t probe_begin = nullptr, probe_end = nullptr;
+    int project_agg = 0;  // LDS-aggregated list filling of the projection: 0 auto, 1 on, 2 off
     int no_records = 0;  // 1: projections never write the rasteriser's records (no-alloc path)
     // Second list set (same tiles_cap x seg_cap): the fitting tail fills it with the NEXT
     // iteration's lists while it still reads the current ones; the sets then swap roles.

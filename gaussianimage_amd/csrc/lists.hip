@@ -366,6 +366,10 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
         case GI2D_OPT_DROP_PENDING:
             ws->chain_pending = false;
             return GI2D_OK;
+        case GI2D_OPT_PROJECT_AGG:
+            if (value < 0 || value > 2) return GI2D_E_INVALID;
+            ws->project_agg = value;
+            return GI2D_OK;
         case GI2D_OPT_RECORDS:
             ws->no_records = value ? 0 : 1;
             ws->rec_valid = false;

@@ -73,16 +73,19 @@ __device__ __forceinline__ Record make_record(float cx, float cy, float ca, floa
     return r;
 }
 
-// (cr, cg, cb): the colour that goes into the record (unused without records).
-__device__ __forceinline__ void project_tail(int g, float mx, float my, float sxx, float sxy,
+// Everything of a projection but the list filling: the five outputs, the record, and the tile
+// box the Gaussian is to be listed in (culled to its support when the opacities are known).
+// Returns false when it is listed nowhere.  (cr, cg, cb_): the colour that goes into the record
+// (unused without records).  want_lists: false skips the box culling.
+__device__ __forceinline__ bool project_body(int g, float mx, float my, float sxx, float sxy,
                                              float syy, int H, int W, int tiles_x, int tiles_y,
-                                             float center_bias, const ProjOut &o,
-                                             const TileLists &tl, const ListCull &cull,
-                                             const RecordSink &rs, float cr, float cg, float cb_)
+                                             float center_bias, const ProjOut &o, bool want_lists,
+                                             const ListCull &cull, const RecordSink &rs, float cr,
+                                             float cg, float cb_, TileBox &box)
 {
     float ca = 0.f, cb = 0.f, cc = 0.f, radius = 0.f, cx = 0.f, cy = 0.f;
     int irad = 0, area = 0;
-    TileBox box = {0, 0, 0, 0};
+    box = TileBox{0, 0, 0, 0};
     if (cov_to_conic_radius(sxx, sxy, syy, ca, cb, cc, radius)) {
         cx = 0.5f * (float)W * mx + 0.5f * (float)W + center_bias;
         cy = 0.5f * (float)H * my + 0.5f * (float)H + center_bias;
@@ -117,11 +120,22 @@ __device__ __forceinline__ void project_tail(int g, float mx, float my, float sx
         dst[1] = rec.r1;
         dst[2] = rec.r2;
     }
-    if (tl.tile_count != nullptr && listed) {
-        if (cull.opacity != nullptr)
-            cull_tile_box(box, cx, cy, kind, rec.r2.z, rec.r2.w, cull.pixel_offset);
-        emit_tiles(g, box, tl.row0, tl.row1, tiles_x, tl.tile_count, tl.seg, tl.C);
-    }
+    if (want_lists && listed && cull.opacity != nullptr)
+        cull_tile_box(box, cx, cy, kind, rec.r2.z, rec.r2.w, cull.pixel_offset);
+    return listed;
+}
+
+__device__ __forceinline__ void project_tail(int g, float mx, float my, float sxx, float sxy,
+                                             float syy, int H, int W, int tiles_x, int tiles_y,
+                                             float center_bias, const ProjOut &o,
+                                             const TileLists &tl, const ListCull &cull,
+                                             const RecordSink &rs, float cr, float cg, float cb_)
+{
+    TileBox box;
+    const bool fill = tl.tile_count != nullptr;
+    const bool listed = project_body(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias,
+                                     o, fill, cull, rs, cr, cg, cb_, box);
+    if (fill && listed) emit_tiles(g, box, tl.row0, tl.row1, tiles_x, tl.tile_count, tl.seg, tl.C);
 }
 
 // dL/dSigma from dL/dconic: with C = Sigma^-1 and V = [[va, vb/2],[vb/2, vc]], G = -C V C;

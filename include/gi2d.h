@@ -89,6 +89,11 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
  * tensors.  0 = the rasteriser always reads the tensors (same results; used by the tests to
  * prove that, and by callers that cannot spare 48 bytes per Gaussian). */
 #define GI2D_OPT_RECORDS 5
+/* GI2D_OPT_PROJECT_AGG: how a projection fills the tile lists.  1 = workgroups of 1024 lanes
+ * count their Gaussians' tiles in LDS and take one counter atomic per tile they touched; 2 = one
+ * counter atomic per (Gaussian, tile) pair; 0 (default) = the first form for batches of four
+ * frames and more, the second otherwise.  A tuning knob: the lists are the same. */
+#define GI2D_OPT_PROJECT_AGG 6
 /* GI2D_OPT_BWD_SERIAL (testing aid): positions the counter of backward launches, from which
  * the stamps of the backward's partial sums derive (1 .. INT_MAX, then the slots are cleared
  * and the stamps start over), so that a test can cross the wrap. */

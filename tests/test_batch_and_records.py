@@ -146,3 +146,32 @@ def test_records_change_no_bit_of_a_fit_or_a_decode(kind):
             out = dec.decode()["render"].clone()
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("kind,F,N,H,W,fp", [("cholesky", 1, 20000, 256, 320, 1.0),
+                                             ("rs", 2, 9000, 96, 128, 2.0),
+                                             ("cholesky", 6, 1500, 33, 17, 1.0),
+                                             ("cholesky", 1, 70000, 512, 768, 1.0)])
+def test_lds_aggregated_list_filling_gives_the_same_lists(kind, F, N, H, W, fp):
+    """The projection that counts its tiles in LDS (one counter atomic per tile a workgroup
+    touches) against the one-atomic-per-pair form: same outputs, same lists, same images --
+    forced on for single frames, for runs of several Gaussians per lane (70 000 Gaussians: the
+    workgroups-per-frame floor), and for a frame smaller than one workgroup."""
+    from gaussianimage_amd import _lib
+    from gaussianimage_amd.pipeline import FrameBatch
+    per = [_inputs(kind, N, 30 + f, fp) for f in range(F)]
+    stack = [None if per[0][k] is None else
+             torch.stack([p[k].reshape(N, -1) for p in per]).to(DEV).contiguous() for k in range(5)]
+    stack[4] = stack[4].reshape(F, N)
+    got = []
+    for mode in (1, 2):
+        b = FrameBatch(F, N, H, W, kind=kind, device=DEV)
+        _lib.check(_lib.lib.gi2d_workspace_set_option(b.ws.handle, _lib.OPT_PROJECT_AGG, mode),
+                   "set_option")
+        for _ in range(3):
+            imgs = b.forward(*stack).clone()
+        offs, ids = b.ws.bins()
+        got.append((imgs, offs, ids, b.xys.clone(), b.radii.clone(), b.conics.clone(),
+                    b.num_tiles_hit.clone()))
+    for x, y in zip(*got):
+        assert torch.equal(x, y)
