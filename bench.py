@@ -233,10 +233,13 @@ def roofline_entry(kernel, timing, N, I_8d, I_held, P, T):
             "frac_lists_held": bheld / t / 1e9 / HBM_PEAK_GBS, **timing}
 
 
-def bench_regions(run, steps, warmup, sync_all, min_time_s, probe=None, probe_every=4):
+def bench_regions(run, steps, warmup, sync_all, min_time_s, probe=None, probe_every=4,
+                  all_agree=lambda done: done):
     """Times regions of EXACTLY `steps` calls of run(), each between synchronisations, until
     `min_time_s` seconds have been timed (at least 3 regions, at most 400).  Returns the list of
-    region times.  `probe`: bracket every `probe_every`-th step's dominant launch."""
+    region times.  `probe`: bracket every `probe_every`-th step's dominant launch.
+    `all_agree(done)`: with several ranks, true only when every rank is done (the ranks must
+    leave the loop together: its synchronisations are collective)."""
     for _ in range(warmup):
         run()
     regions = []
@@ -251,9 +254,13 @@ def bench_regions(run, steps, warmup, sync_all, min_time_s, probe=None, probe_ev
                     probe.disarm()
                 else:
                     run()
-            sync_all()
+            # (the clock stops when this rank's own work has completed; the barrier that closes
+            # the bracket follows, and the slowest rank's time is what gets reported)
+            torch.cuda.synchronize()
             regions.append(time.perf_counter() - t0)
-            if len(regions) >= 400 or (len(regions) >= 3 and sum(regions) >= min_time_s):
+            sync_all()
+            if all_agree(len(regions) >= 400 or
+                         (len(regions) >= 3 and sum(regions) >= min_time_s)):
                 return regions
 
 
@@ -656,9 +663,17 @@ def main():
     I_held = batch.intersections()
     run()
 
+    def all_agree(done):
+        if not distributed:
+            return done
+        flag = torch.tensor([1 if done else 0], dtype=torch.int32,
+                            device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
     probe = Probe(batch.ws, "raster_fwd", 256)
     regions = bench_regions(run, args.steps, args.warmup, sync_all, args.min_time_ms * 1e-3,
-                            probe=probe)
+                            probe=probe, all_agree=all_agree)
     el = sorted(regions)[len(regions) // 2]
     if distributed:
         t = torch.tensor([el], dtype=torch.float64,
