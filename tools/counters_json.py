@@ -29,7 +29,8 @@ def avg(kernel_part, counter, skip_first=2):
 
 out = {"source": source}
 for tag, part in (("raster_fwd", "rasterize_sum_fwd_kernel<true, false, 1, 1, true>"),
-                  ("project", "project_cholesky_fwd_kernel<false>")):
+                  ("project", "project_agg_fwd_kernel<false>"),
+                  ("project_direct", "project_cholesky_fwd_kernel<false>")):
     f, w = avg(part, "FETCH_SIZE"), avg(part, "WRITE_SIZE")
     if f is not None and w is not None:
         out[tag + "_fetch_bytes_x2"] = f * 1024 * 2
