@@ -282,6 +282,7 @@ def bench_model_loops(name, device, steps):
     L2 loss, backward, PSNR .item(), Adan step, StepLR -- /root/reference/train.py:141-145) and
     the FPS loop (100 x model() under eval + no_grad, wall clock --
     /root/reference/train.py:242-249; synchronised at both ends here)."""
+    from gaussianimage_amd import ops
     from gaussianimage_amd._testing import harness, synth
     H, W, N, kind, _ = WORKLOADS[name]
     torch.manual_seed(1)
@@ -290,7 +291,31 @@ def bench_model_loops(name, device, steps):
     else:
         model = harness.RSImageModel(N, H, W, device)
     gt = synth.target_image(H, W).to(device)
-    out = {}
+    out = {"operator_binding": "compiled (csrc/torch_ops.cpp)" if ops.compiled_binding()
+           else "ctypes (ops.py)"}
+    if ops.compiled_binding():
+        # the same two loops through the ctypes binding of the same kernels, for comparison
+        prev = ops.use_compiled(False)
+        try:
+            for _ in range(10):
+                model.train_iter(gt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model.train_iter(gt)
+            torch.cuda.synchronize()
+            out["train_step_ms_ctypes_binding"] = (time.perf_counter() - t0) / steps * 1e3
+            with torch.no_grad():
+                for _ in range(10):
+                    model()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    model()
+                torch.cuda.synchronize()
+                out["reference_fps_loop_ctypes_binding"] = 100 / (time.perf_counter() - t0)
+        finally:
+            ops.use_compiled(prev)
     model.train()
     for _ in range(10):
         model.train_iter(gt)

@@ -77,5 +77,57 @@ def build_native(force=False, extra_flags=(), verbose=False, jobs=None):
     return LIB
 
 
+TORCH_OPS_SRC = os.path.join(CSRC, "torch_ops.cpp")
+TORCH_OPS_LIB = os.path.join(_HERE, "_torch_ops.so")
+
+
+def torch_ops_stale():
+    if not os.path.exists(TORCH_OPS_LIB):
+        return True
+    t = os.path.getmtime(TORCH_OPS_LIB)
+    deps = [TORCH_OPS_SRC, os.path.join(os.path.dirname(_HERE), "include", "gi2d.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def torch_ops_id():
+    """Hash of what the compiled binding is built from, and the torch it is built against."""
+    import torch
+    h = hashlib.sha256()
+    for d in (TORCH_OPS_SRC, os.path.join(os.path.dirname(_HERE), "include", "gi2d.h")):
+        h.update(open(d, "rb").read())
+    return h.hexdigest()[:16] + "/torch-" + torch.__version__
+
+
+def build_torch_ops(force=False, verbose=False):
+    """The compiled binding of the three operators (csrc/torch_ops.cpp -> _torch_ops.so): host
+    code only, compiled with g++ against the installed torch's headers and linked to libgi2d.so
+    (found at run time next to it: rpath $ORIGIN/csrc).  No device code, no JIT cache."""
+    if not force and not torch_ops_stale():
+        return TORCH_OPS_LIB
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-shared",
+           "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_torch_ops", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           '-DGI2D_TORCH_OPS_ID="%s"' % torch_ops_id(),
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-Wno-attributes"]
+    for inc in ce.include_paths():
+        cmd += ["-isystem", inc]
+    cmd += ["-isystem", "/opt/rocm/include", "-I", sysconfig.get_paths()["include"],
+            "-I", os.path.join(os.path.dirname(_HERE), "include"), TORCH_OPS_SRC, "-o",
+            TORCH_OPS_LIB]
+    for lib_dir in ce.library_paths():
+        cmd += ["-L", lib_dir]
+    cmd += ["-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+            "-L", CSRC, "-lgi2d", "-Wl,-rpath,$ORIGIN/csrc"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TORCH_OPS_LIB
+
+
 if __name__ == "__main__":
     print(build_native(force=True, verbose=True))
+    print(build_torch_ops(force=True, verbose=True))

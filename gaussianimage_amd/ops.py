@@ -7,6 +7,13 @@ error behaviour of the operators the reference imports
 /root/reference/gaussianimage_rs.py:1-2,75-77) and run on the HIP kernels of
 ``csrc/*.hip`` through the C ABI.  PyTorch is used for device memory, the
 current stream and autograd bookkeeping only.
+
+Two bindings of the same three operators exist: the compiled one
+(``csrc/torch_ops.cpp`` -> ``_torch_ops.so``: C++ autograd functions, a third of the host
+time per call) and the ctypes one in this file.  The compiled binding is used when its
+library is present and matches its sources and the running torch; ``use_compiled(False)``
+(or ``GI2D_PY_BINDING=1``) selects the ctypes binding.  Both launch the same kernels and
+give the same bits; each keeps its own per-stream workspaces.
 """
 import ctypes
 import os
@@ -19,9 +26,54 @@ from . import _lib
 from ._lib import BLOCK, Conv, check, default_conv, lib
 
 __all__ = ["project_gaussians_2d", "project_gaussians_2d_scale_rot", "rasterize_gaussians_sum",
-           "rasterize_gaussians_sum_multi", "Workspace", "get_workspace", "set_conventions", "get_conventions"]
+           "rasterize_gaussians_sum_multi", "Workspace", "get_workspace", "set_conventions",
+           "get_conventions", "use_compiled", "compiled_binding", "reset_workspace"]
 
 _CONV = default_conv()
+
+
+def _load_compiled():
+    """The compiled binding, or (None, reason) when it is absent or does not match."""
+    if os.environ.get("GI2D_PY_BINDING", "0") == "1":
+        return None, "GI2D_PY_BINDING=1"
+    try:
+        from . import _torch_ops as mod
+    except ImportError as e:
+        return None, "not built (python -m gaussianimage_amd.build): %s" % e
+    from . import build
+    try:
+        want = build.torch_ops_id()
+    except OSError:
+        want = None  # an installation without the sources
+    if want is not None and mod.build_id() != want and \
+            os.environ.get("GI2D_ALLOW_STALE", "0") != "1":
+        return None, "built from other sources or another torch (%s, now %s); rebuild with " \
+                     "python -m gaussianimage_amd.build" % (mod.build_id(), want)
+    mod.init(ctypes.addressof(_CONV), _lib.Gi2dError)
+    return mod, None
+
+
+_C, _C_WHY_NOT = _load_compiled()
+if _C is None and _C_WHY_NOT != "GI2D_PY_BINDING=1":
+    warnings.warn("gaussianimage_amd: the compiled operator binding is not used (%s); the ctypes "
+                  "binding runs the same kernels with more host time per call" % _C_WHY_NOT,
+                  RuntimeWarning)
+_USE_C = _C is not None
+
+
+def use_compiled(on=True):
+    """Selects the compiled (True) or the ctypes (False) binding of the three operators;
+    returns the previous choice.  Raises when the compiled binding is not available."""
+    global _USE_C
+    if on and _C is None:
+        raise RuntimeError("the compiled binding is not available: %s" % _C_WHY_NOT)
+    prev, _USE_C = _USE_C, bool(on)
+    return prev
+
+
+def compiled_binding():
+    """True when the operators currently run through the compiled binding."""
+    return _USE_C
 
 
 def set_conventions(**kw):
@@ -186,6 +238,33 @@ class Workspace:
         return offs.cpu(), ids[:total].cpu()
 
 
+class _CompiledWorkspace(Workspace):
+    """The same interface over a workspace the compiled binding owns: the list-reuse state
+    lives on the C++ side, where the compiled operators read and write it."""
+
+    def __init__(self, device, state):
+        self.device = torch.device(device)
+        self._st = state
+        self.handle = ctypes.c_void_p(state.handle)
+        self.rows = (0, 2 ** 31 - 1)
+
+    def __del__(self):
+        self.handle = None  # (the compiled binding keeps its workspaces for the process's life)
+
+    key = property(lambda self: self._st.has_lists or None,
+                   lambda self, v: self._st.invalidate(False))
+    counted_key = property(lambda self: None, lambda self, v: self._st.invalidate(True))
+    late_overflows = property(lambda self: self._st.late_overflows,
+                              lambda self, v: setattr(self._st, "late_overflows", v))
+    strict = property(lambda self: self._st.strict,
+                      lambda self, v: setattr(self._st, "strict", bool(v)))
+    sync_binning = property(lambda self: self._st.sync_binning,
+                            lambda self, v: setattr(self._st, "sync_binning", bool(v)))
+
+    def bin(self, xys, radii, H, W, flags=0, force=False):
+        self._st.bin(xys, radii, int(H), int(W), int(flags), bool(force))
+
+
 _WORKSPACES = {}
 _WS_LOCK = threading.Lock()
 
@@ -198,15 +277,33 @@ def get_workspace(device):
     if not isinstance(device, torch.device):
         device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, _stream(device) or 0)
+    stream = _stream(device) or 0
+    key = (idx, stream, _USE_C)  # (each binding has its own)
     ws = _WORKSPACES.get(key)  # (entries are only ever added)
     if ws is not None:
         return ws
     with _WS_LOCK:
         ws = _WORKSPACES.get(key)
         if ws is None:
-            ws = _WORKSPACES[key] = Workspace(torch.device("cuda", idx))
+            dev = torch.device("cuda", idx)
+            ws = _WORKSPACES[key] = (_CompiledWorkspace(dev, _C.workspace(idx, stream)) if _USE_C
+                                     else Workspace(dev))
         return ws
+
+
+def reset_workspace(device):
+    """Drops the operators' workspace of the current stream of ``device`` (both bindings): the
+    next call starts from a fresh one, with lists sized anew.  The caller makes sure no work
+    that uses the old lists is still queued."""
+    if not isinstance(device, torch.device):
+        device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    stream = _stream(device) or 0
+    with _WS_LOCK:
+        _WORKSPACES.pop((idx, stream, False), None)
+        _WORKSPACES.pop((idx, stream, True), None)
+    if _C is not None:
+        _C.drop_workspace(idx, stream)
 
 
 def _tile_bounds_check(name, H, W, tile_bounds):
@@ -440,6 +537,8 @@ def project_gaussians_2d(means2d, L_elements, img_height, img_width, tile_bounds
     """``gsplat.project_gaussians_2d.project_gaussians_2d`` of the reference
     (/root/reference/gaussianimage_cholesky.py:77).  Returns
     ``(xys[N,2], depths[N], radii[N] int32, conics[N,3], num_tiles_hit[N] int32)``."""
+    if _USE_C:
+        return _C.project_gaussians_2d(means2d, L_elements, img_height, img_width, tile_bounds)
     if means2d.ndimension() != 2 or means2d.shape[1] != 2:
         raise ValueError("means2d must have shape (N, 2)")
     if L_elements.ndimension() != 2 or L_elements.shape != (means2d.shape[0], 3):
@@ -452,6 +551,9 @@ def project_gaussians_2d_scale_rot(means2d, scales2d, rotation, img_height, img_
                                    tile_bounds):
     """``gsplat.project_gaussians_2d_scale_rot.project_gaussians_2d_scale_rot``
     (/root/reference/gaussianimage_rs.py:75); ``rotation`` in radians, shape (N, 1)."""
+    if _USE_C:
+        return _C.project_gaussians_2d_scale_rot(means2d, scales2d, rotation, img_height,
+                                                 img_width, tile_bounds)
     N = means2d.shape[0]
     if means2d.ndimension() != 2 or means2d.shape[1] != 2:
         raise ValueError("means2d must have shape (N, 2)")
@@ -470,6 +572,9 @@ def rasterize_gaussians_sum(xys, depths, radii, conics, num_tiles_hit, colors, o
     (/root/reference/gaussianimage_cholesky.py:81-82): the accumulated sum
     ``out[p] = sum_g colors[g] * min(cap, opacity[g] * exp(-sigma_g(p)))`` over the Gaussians
     binned to the pixel's tile; ``[H, W, 3]`` float32."""
+    if _USE_C and not return_alpha:
+        return _C.rasterize_gaussians_sum(xys, radii, conics, colors, opacity, img_height,
+                                          img_width, BLOCK_H, BLOCK_W, background)
     if colors.ndimension() != 2:
         raise ValueError("colors must have dimensions (N, D)")
     if opacity.ndimension() != 2:

@@ -450,14 +450,14 @@ def test_asynchronous_overflow_is_loud_and_repaired(ops, oracle):
     nth = torch.zeros(N, dtype=torch.int32, device=DEV)
     # a fresh workspace: the shared one has grown in earlier tests and never shrinks; strict, so
     # that the report of the earlier frame's overflow comes as the exception it is underneath
-    key = (torch.device(DEV).index or 0, 0)
-    saved = ops._WORKSPACES.get(key)
-    ops._WORKSPACES[key] = ops.Workspace(DEV)
-    ops._WORKSPACES[key].strict = True
+    torch.cuda.synchronize()
+    ops.reset_workspace(DEV)
+    ops.get_workspace(DEV).strict = True
     try:
         _overflow_scenario(ops, oracle, xys, small, big, conics, col, opa, z, nth, H, W)
     finally:
-        ops._WORKSPACES[key] = saved
+        torch.cuda.synchronize()
+        ops.reset_workspace(DEV)
 
 
 def _overflow_scenario(ops, oracle, xys, small, big, conics, col, opa, z, nth, H, W):
@@ -1214,7 +1214,8 @@ def test_late_overflow_report_does_not_stop_the_operators(ops, oracle):
     small = torch.full((N,), 2, dtype=torch.int32, device=DEV)
     big = torch.full((N,), 60, dtype=torch.int32, device=DEV)
     st = torch.cuda.Stream()
-    with torch.cuda.stream(st):     # a stream of its own: a fresh workspace
+    with torch.cuda.stream(st):     # a stream of its own, and a fresh workspace on it
+        ops.reset_workspace(DEV)
         ws = ops.get_workspace(DEV)
         for _ in range(3):
             ops.rasterize_gaussians_sum(xys.clone(), z, small, conics, nth, col, opa, H, W, 16, 16)
