@@ -182,8 +182,10 @@ class Probe:
     `disarm()` after it; `ms()` reads the durations once everything has completed."""
 
     def __init__(self, ws, kernel, pairs):
+        """`ws`: a workspace, or a callable that returns the workspace the NEXT call will use."""
         from gaussianimage_amd import _lib
         self._lib, self.ws, self.kernel = _lib, ws, _lib.PROBE[kernel]
+        self.armed = None
         self.pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                       for _ in range(pairs)]
         for a, b in self.pairs:   # a torch event gets its handle when first recorded
@@ -194,11 +196,14 @@ class Probe:
     def arm(self):
         a, b = self.pairs[self.used]
         self.used += 1
-        self._lib.lib.gi2d_workspace_set_probe(self.ws.handle, self.kernel, a.cuda_event,
+        self.armed = self.ws() if callable(self.ws) else self.ws
+        self._lib.lib.gi2d_workspace_set_probe(self.armed.handle, self.kernel, a.cuda_event,
                                                b.cuda_event)
 
     def disarm(self):
-        self._lib.lib.gi2d_workspace_set_probe(self.ws.handle, 0, None, None)
+        if self.armed is not None:
+            self._lib.lib.gi2d_workspace_set_probe(self.armed.handle, 0, None, None)
+            self.armed = None
 
     def ms(self):
         return sorted(a.elapsed_time(b) for a, b in self.pairs[:self.used])
@@ -588,6 +593,15 @@ def secondary(args, device, batch, run, batch_in, B, I_8d, I_held, raster_batch_
     ex["pair_evals_per_s_batched"] = I_held * 256 / (raster_batch_ms * 1e-3)
     if not args.no_concurrent:
         ex.update(bench_concurrent(args.workload, inputs, device, max(args.steps, 200)))
+        # the headline's batches with 2 and 3 of them in flight on streams of their own (the
+        # projection of one under the rasteriser of another); the headline itself is one batch
+        # at a time on one stream
+        from gaussianimage_amd.pipeline import BatchRing
+        for depth in (2, 3):
+            ring = BatchRing(B, N, H, W, kind=kind, device=device, depth=depth)
+            ms = bench_region(lambda: ring.render(*batch_in), 200, 40)
+            ex["fps_batches_in_flight_%d" % depth] = B * 1e3 / ms
+            del ring
         sweep = {}
         for b in (1, 2, 4, 16):   # the headline call at other batch sizes
             fb, frun = bound_batch(args.workload, device, b)
@@ -638,6 +652,9 @@ def main():
                          "a second workload blur a profiler's per-kernel averages)")
     ap.add_argument("--raster-ppl", type=int, default=0, choices=[0, 1, 2, 4],
                     help="pixels per lane of the forward rasteriser (0 = the library's choice)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="steps in flight: consecutive steps alternate between this many batch "
+                         "objects, each on a stream of its own")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -696,8 +713,29 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
-    probe = Probe(batch.ws, "raster_fwd", 256)
-    regions = bench_regions(run, args.steps, args.warmup, sync_all, args.min_time_ms * 1e-3,
+    # --in-flight D > 1: consecutive steps go to D batch objects, each with its own workspace,
+    # outputs and (default-priority) stream, so that the projection of one step's batch runs
+    # under the rasteriser of the step before; every step is still one call for one batch, and
+    # a timed region still ends when all of its steps have completed.
+    D = max(1, args.in_flight)
+    step_run = run
+    if D > 1:
+        from gaussianimage_amd.pipeline import BatchRing
+        ring = BatchRing(B, N, H, W, kind=kind, device=device, depth=D)
+        if args.raster_ppl:
+            for fb in ring.slots:
+                fb.ws.set_raster_ppl(args.raster_ppl)
+
+        def step_run():
+            ring.render(*batch_in)
+
+        for _ in range(3 * D):
+            step_run()
+        torch.cuda.synchronize()
+        probe = Probe(lambda: ring.next_slot().ws, "raster_fwd", 256)
+    else:
+        probe = Probe(batch.ws, "raster_fwd", 256)
+    regions = bench_regions(step_run, args.steps, args.warmup, sync_all, args.min_time_ms * 1e-3,
                             probe=probe, all_agree=all_agree)
     el = sorted(regions)[len(regions) // 2]
     if distributed:
@@ -744,7 +782,7 @@ def main():
                                f"model-init distribution, footprint x{fp}; one step = one batch "
                                f"of {B} different frames (seeds {1 + rank * B}..{rank * B + B}) "
                                "in one call",
-                   "frames_per_step": B, "intersections_per_frame": I_8d / B,
+                   "frames_per_step": B, "steps_in_flight": D, "intersections_per_frame": I_8d / B,
                    "list_entries_per_frame": I_held / B, "tiles_per_frame": T,
                    "parallelism": "1 process/GPU, independent frames per rank"},
         "timed_regions": len(regions), "frames_timed": len(regions) * args.steps * B,

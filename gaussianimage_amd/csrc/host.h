@@ -42,7 +42,11 @@ struct gi2d_workspace {
     // instrumentation (gi2d_workspace_set_probe): events recorded around one kind of launch
     int probe_kernel = 0;
     hipEvent_t probe_begin = nullptr, probe_end = nullptr;
-    int project_agg = 0;  // LDS-aggregated list filling of the projection: 0 auto, 1 on, 2 off
+    // list filling of a projection: 0 auto, 1 aggregated in LDS per workgroup, 2 direct (one
+    // counter atomic per pair), 3 by bands of tile rows (no counter atomics)
+    int project_agg = 0;
+    int *d_box = nullptr;            // packed tile boxes of the band-wise list filling
+    int64_t box_cap = 0;
     int no_records = 0;  // 1: projections never write the rasteriser's records (no-alloc path)
     // Second list set (same tiles_cap x seg_cap): the fitting tail fills it with the NEXT
     // iteration's lists while it still reads the current ones; the sets then swap roles.
@@ -141,6 +145,7 @@ static inline int ws_tiles(const gi2d_workspace *ws) { return ws->frames * ws_ti
 // lists.hip
 int ensure_lists(gi2d_workspace *ws, int T, int C);
 int ensure_records(gi2d_workspace *ws, int64_t count);
+int ensure_boxes(gi2d_workspace *ws, int64_t count);
 int bin_tiles_impl(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
                    int tiles_y, int flags, void *stream, int frames);
 int wanted_cap(const gi2d_workspace *ws, long long seen);

@@ -184,6 +184,19 @@ int ensure_records(gi2d_workspace *ws, int64_t count)
     return GI2D_OK;
 }
 
+// One packed tile box per Gaussian for `count` Gaussians; the device is current.
+int ensure_boxes(gi2d_workspace *ws, int64_t count)
+{
+    if (ws->box_cap >= count) return GI2D_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (ws->d_box) (void)hipFree(ws->d_box);
+    ws->d_box = nullptr;
+    ws->box_cap = 0;
+    HIP_TRY(hipMalloc(&ws->d_box, sizeof(int) * (size_t)count));
+    ws->box_cap = count;
+    return GI2D_OK;
+}
+
 // Prepares ws for a projection that also fills the tile lists.  Leaves ws->prefilled false when
 // the shape is new (the lists' capacity is unknown): gi2d_bin_tiles then bins synchronously.
 int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int frames, hipStream_t st)
@@ -338,6 +351,7 @@ int gi2d_workspace_destroy(gi2d_workspace *ws)
     free_alt_lists(ws);
     if (ws->d_gslots) (void)hipFree(ws->d_gslots);
     if (ws->d_rec) (void)hipFree(ws->d_rec);
+    if (ws->d_box) (void)hipFree(ws->d_box);
     if (ws->d_status) (void)hipFree(ws->d_status);
     if (ws->h_status) (void)hipHostFree(ws->h_status);
     delete ws;
@@ -367,7 +381,7 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
             ws->chain_pending = false;
             return GI2D_OK;
         case GI2D_OPT_PROJECT_AGG:
-            if (value < 0 || value > 2) return GI2D_E_INVALID;
+            if (value < 0 || value > 3) return GI2D_E_INVALID;
             ws->project_agg = value;
             return GI2D_OK;
         case GI2D_OPT_RECORDS:

@@ -260,6 +260,109 @@ __global__ __launch_bounds__(AGG_THREADS) void project_agg_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// The projection of a batch with the list filling by BANDS of tile rows: no counter atomics at
+// all.  Two launches:
+//   1. project_boxes_fwd_kernel -- one lane per Gaussian, the whole chip: outputs, record, and
+//      the Gaussian's (culled) tile box packed into one word;
+//   2. fill_bands_kernel -- one workgroup of 1024 lanes per (band of tile rows, frame) OWNS the
+//      band's tiles: it reads every box of its frame (4 bytes per Gaussian, from L2 after the
+//      first band), keeps the rows of its band, and hands out list places with returning LDS
+//      atomics on counters that live in LDS; at the end it stores the counters.  No other
+//      workgroup touches those tiles, so the global counters see one plain store per tile.
+// A workgroup scans N boxes whatever the band holds, so this form is for frames of moderate N
+// split into enough bands to fill the chip: batches.  Lists are the same sets as the other
+// forms' (the rasteriser's sort restores the order).  Each side < 256 tiles.
+// ------------------------------------------------------------------------------------------
+#define BAND_MAX_ROUNDS 64  // N <= BAND_MAX_ROUNDS * AGG_THREADS per frame
+
+template <bool RS>
+__global__ __launch_bounds__(PG_THREADS) void project_boxes_fwd_kernel(
+    const float *__restrict__ means, const float *__restrict__ cov_a,
+    const float *__restrict__ cov_b, ProjArgs a, int *__restrict__ boxes)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (g == 0 && f == 0) publish_status(a.status, a.h_status, a.generation);
+    if (g >= a.N) return;
+    to_frame(a, f);
+    means += (size_t)f * 2 * a.N;
+    cov_a += (size_t)f * (RS ? 2 : 3) * a.N;
+    if (RS) cov_b += (size_t)f * a.N;
+    const float mx = means[2 * g], my = means[2 * g + 1];
+    float sxx, sxy, syy;
+    if (RS) {
+        float s, c;
+        gi2d_sincos_f32(cov_b[g], &s, &c);
+        const float s1 = cov_a[2 * g], s2 = cov_a[2 * g + 1];
+        const float q1 = s1 * s1, q2 = s2 * s2;
+        sxx = c * c * q1 + s * s * q2;
+        sxy = c * s * (q1 - q2);
+        syy = s * s * q1 + c * c * q2;
+    } else {
+        const float l11 = cov_a[3 * g], l21 = cov_a[3 * g + 1], l22 = cov_a[3 * g + 2];
+        sxx = l11 * l11;
+        sxy = l11 * l21;
+        syy = l21 * l21 + l22 * l22;
+    }
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    if (a.rec.rec != nullptr) {
+        cr = a.rec_colors[3 * g];
+        cg = a.rec_colors[3 * g + 1];
+        cb = a.rec_colors[3 * g + 2];
+    }
+    TileBox box;
+    const bool listed = project_body(g, mx, my, sxx, sxy, syy, a.H, a.W, a.tiles_x, a.tiles_y,
+                                     a.center_bias, a.out, true, a.cull, a.rec, cr, cg, cb, box);
+    int packed = 0;  // (an empty box: x0 = x1)
+    if (listed && box.x1 > box.x0 && box.y1 > box.y0)
+        packed = box.x0 | (box.x1 << 8) | (box.y0 << 16) | (box.y1 << 24);
+    boxes[(size_t)f * a.N + g] = packed;
+}
+
+__global__ __launch_bounds__(AGG_THREADS) void fill_bands_kernel(
+    const int *__restrict__ boxes, int N, int tiles_x, int tiles_y, int rows_per_band,
+    int tiles_per_frame, int *__restrict__ tile_count, int *__restrict__ seg, int C)
+{
+    __shared__ int cnt[AGG_MAX_TILES];
+    const int tid = threadIdx.x, f = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_band, r1 = min(tiles_y, r0 + rows_per_band);
+    const int band_tiles = (r1 - r0) * tiles_x;
+    boxes += (size_t)f * N;
+    const size_t t0 = (size_t)f * tiles_per_frame + (size_t)r0 * tiles_x;  // the band's first tile
+    for (int t = tid; t < band_tiles; t += AGG_THREADS) cnt[t] = 0;
+    __syncthreads();
+    // (a lane's loads are issued eight at a time: the scan is a chain of memory round trips
+    // otherwise, one per 1024 Gaussians)
+    constexpr int PF = 8;
+    for (int gb = tid; gb < N; gb += PF * AGG_THREADS) {
+        int bx[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int g = gb + k * AGG_THREADS;
+            bx[k] = g < N ? boxes[g] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int b = bx[k], g = gb + k * AGG_THREADS;
+            const int y0 = max((b >> 16) & 255, r0), y1 = min((b >> 24) & 255, r1);
+            if (y0 >= y1) continue;  // (an empty box has y0 = y1 = 0 too)
+            const int x0 = b & 255, x1 = (b >> 8) & 255;
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) {
+                    const int t = (ty - r0) * tiles_x + tx;
+                    const int pos = atomicAdd(&cnt[t], 1);
+                    // (ids beyond a segment's capacity are dropped; the counter has counted them)
+                    if (pos < C) seg[(t0 + t) * C + pos] = g;
+                }
+        }
+    }
+    __syncthreads();
+    // (the counters were zero: the rasteriser returns them to zero after reading them)
+    for (int t = tid; t < band_tiles; t += AGG_THREADS)
+        if (cnt[t] > 0) tile_count[(t0 + t) * CNT_STRIDE] = cnt[t];
+}
+
+// ------------------------------------------------------------------------------------------
 // Codec decode (decompress_wo_ec, gaussianimage_cholesky.py:161-166 / gaussianimage_rs.py:132-139):
 //   means    = tanh(float(xyz_half))
 //   cholesky = code * scale + beta, then + (0.5, 0, 0.5)       (quantize.py:86-87)
@@ -517,12 +620,32 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
     const dim3 grid(cdiv(N, PG_THREADS), frames), block(PG_THREADS);
     // The LDS-aggregated list filling pays when its few large workgroups still fill the chip:
     // batches.  One frame keeps the direct kernels (GI2D_OPT_PROJECT_AGG forces either form).
-    bool agg = fill && !codec && !raw && tiles_x < 256 && tiles_y < 256 &&
-               a.tiles_per_frame <= AGG_MAX_TILES && ws->pre_r0 == 0 && ws->pre_r1 == tiles_y;
-    if (agg) agg = ws->project_agg == 1 || (ws->project_agg == 0 && frames >= 4);
+    const bool whole = fill && !codec && !raw && tiles_x < 256 && tiles_y < 256 &&
+                       ws->pre_r0 == 0 && ws->pre_r1 == tiles_y;
+    bool agg = whole && a.tiles_per_frame <= AGG_MAX_TILES;
+    // bands: enough of them to fill the chip, each within the LDS counters; every workgroup
+    // scans all N boxes of its frame, which bounds N
+    int bands = whole ? max(1, min(tiles_y, 256 / frames)) : 0;
+    int rows_per_band = whole ? cdiv(tiles_y, bands) : 0;
+    bool by_bands = whole && rows_per_band * tiles_x <= AGG_MAX_TILES &&
+                    N <= BAND_MAX_ROUNDS * AGG_THREADS;
+    // (on request only: at 8 x 30 000 Gaussians its two launches take 11 + 13 us against 19.8 us
+    // for the aggregated form -- the scan of all boxes by every band is a chain of memory rounds)
+    if (by_bands) by_bands = ws->project_agg == 3;
+    if (by_bands && ensure_boxes(ws, (int64_t)frames * N) != GI2D_OK) by_bands = false;
+    if (agg) agg = !by_bands && (ws->project_agg == 1 || (ws->project_agg == 0 && frames >= 4));
     {
     Probe probe(fill ? ws : nullptr, GI2D_PROBE_PROJECT, st);
-    if (agg) {
+    if (by_bands) {
+        if (kind == 0)
+            project_boxes_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, cov_b, a, ws->d_box);
+        else
+            project_boxes_fwd_kernel<true><<<grid, block, 0, st>>>(means, cov_a, cov_b, a, ws->d_box);
+        bands = cdiv(tiles_y, rows_per_band);
+        fill_bands_kernel<<<dim3(bands, frames), AGG_THREADS, 0, st>>>(
+            ws->d_box, N, tiles_x, tiles_y, rows_per_band, a.tiles_per_frame, a.lists.tile_count,
+            a.lists.seg, a.lists.C);
+    } else if (agg) {
         // workgroups per frame: enough to spread over the chip, few enough to share counters
         // (measured at 8 x 30 000 Gaussians on 768x512: 8 / 16 / 30 workgroups per frame give
         // 21.3 / 19.9 / 20.5 us against 35 us for the direct kernel)

@@ -91,8 +91,11 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
 #define GI2D_OPT_RECORDS 5
 /* GI2D_OPT_PROJECT_AGG: how a projection fills the tile lists.  1 = workgroups of 1024 lanes
  * count their Gaussians' tiles in LDS and take one counter atomic per tile they touched; 2 = one
- * counter atomic per (Gaussian, tile) pair; 0 (default) = the first form for batches of four
- * frames and more, the second otherwise.  A tuning knob: the lists are the same. */
+ * counter atomic per (Gaussian, tile) pair; 3 = by bands of tile rows: the projection leaves a
+ * packed tile box per Gaussian and a second launch, one workgroup per (band, frame), owns the
+ * band's tiles and needs no counter atomics (frames of at most 65 536 Gaussians; two launches,
+ * measured slower than form 1 at 8 x 30 000 Gaussians); 0 (default) = form 1 for batches of four
+ * frames and more, form 2 otherwise.  A tuning knob: the lists are the same. */
 #define GI2D_OPT_PROJECT_AGG 6
 /* GI2D_OPT_BWD_SERIAL (testing aid): positions the counter of backward launches, from which
  * the stamps of the backward's partial sums derive (1 .. INT_MAX, then the slots are cleared

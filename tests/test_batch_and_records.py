@@ -151,12 +151,16 @@ def test_records_change_no_bit_of_a_fit_or_a_decode(kind):
 @pytest.mark.parametrize("kind,F,N,H,W,fp", [("cholesky", 1, 20000, 256, 320, 1.0),
                                              ("rs", 2, 9000, 96, 128, 2.0),
                                              ("cholesky", 6, 1500, 33, 17, 1.0),
-                                             ("cholesky", 1, 70000, 512, 768, 1.0)])
-def test_lds_aggregated_list_filling_gives_the_same_lists(kind, F, N, H, W, fp):
+                                             ("cholesky", 1, 70000, 512, 768, 1.0),
+                                             ("rs", 5, 30000, 512, 768, 1.0),
+                                             ("cholesky", 3, 4000, 700, 40, 3.0)])
+def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
     """The projection that counts its tiles in LDS (one counter atomic per tile a workgroup
-    touches) against the one-atomic-per-pair form: same outputs, same lists, same images --
-    forced on for single frames, for runs of several Gaussians per lane (70 000 Gaussians: the
-    workgroups-per-frame floor), and for a frame smaller than one workgroup."""
+    touches) and the one that fills the lists by bands of tile rows (no counter atomics) against
+    the one-atomic-per-pair form: same outputs, same lists, same images -- forced on for single
+    frames, for runs of several Gaussians per lane (70 000 Gaussians: the workgroups-per-frame
+    floor of the first, beyond the limit of the second), for a frame smaller than one workgroup
+    and for a tall frame whose bands hold several tile rows."""
     from gaussianimage_amd import _lib
     from gaussianimage_amd.pipeline import FrameBatch
     per = [_inputs(kind, N, 30 + f, fp) for f in range(F)]
@@ -164,7 +168,7 @@ def test_lds_aggregated_list_filling_gives_the_same_lists(kind, F, N, H, W, fp):
              torch.stack([p[k].reshape(N, -1) for p in per]).to(DEV).contiguous() for k in range(5)]
     stack[4] = stack[4].reshape(F, N)
     got = []
-    for mode in (1, 2):
+    for mode in (2, 1, 3):
         b = FrameBatch(F, N, H, W, kind=kind, device=DEV)
         _lib.check(_lib.lib.gi2d_workspace_set_option(b.ws.handle, _lib.OPT_PROJECT_AGG, mode),
                    "set_option")
@@ -173,5 +177,40 @@ def test_lds_aggregated_list_filling_gives_the_same_lists(kind, F, N, H, W, fp):
         offs, ids = b.ws.bins()
         got.append((imgs, offs, ids, b.xys.clone(), b.radii.clone(), b.conics.clone(),
                     b.num_tiles_hit.clone()))
-    for x, y in zip(*got):
-        assert torch.equal(x, y)
+    for other in got[1:]:
+        for x, y in zip(got[0], other):
+            assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_batch_ring_gives_the_bits_of_the_batch_call(depth):
+    """Batches in flight on two streams (the projection of one under the rasteriser of the one
+    before): every image is the one-call batch's, whatever the depth and whichever slot."""
+    from gaussianimage_amd.pipeline import BatchRing, FrameBatch
+    kind, F, N, H, W = "cholesky", 4, 6000, 160, 208
+    batches = []
+    for s in range(3):
+        per = [_inputs(kind, N, 70 + 10 * s + f, 1.0) for f in range(F)]
+        stack = [None if per[0][k] is None else
+                 torch.stack([p[k].reshape(N, -1) for p in per]).to(DEV).contiguous()
+                 for k in range(5)]
+        stack[4] = stack[4].reshape(F, N)
+        batches.append(stack)
+    ref = FrameBatch(F, N, H, W, kind=kind, device=DEV)
+    want = [ref.forward(*b).clone() for b in batches]
+    torch.cuda.synchronize()
+    ring = BatchRing(F, N, H, W, kind=kind, device=DEV, depth=depth)
+    for rep in range(7):
+        b = rep % 3
+        imgs, done = ring.render(*batches[b])
+        done.synchronize()
+        assert torch.equal(imgs, want[b]), (depth, rep)
+    # and without waiting in between: the slots' buffers are only reused `depth` calls later
+    outs = []
+    for rep in range(depth):
+        imgs, done = ring.render(*batches[rep % 3])
+        outs.append((imgs, done, rep % 3))
+    for imgs, done, b in outs:
+        done.synchronize()
+        assert torch.equal(imgs, want[b])
+    ring.synchronize()
