@@ -571,16 +571,21 @@ def rasterize_gaussians_sum(xys, depths, radii, conics, num_tiles_hit, colors, o
     """``gsplat.rasterize_sum.rasterize_gaussians_sum`` of the reference
     (/root/reference/gaussianimage_cholesky.py:81-82): the accumulated sum
     ``out[p] = sum_g colors[g] * min(cap, opacity[g] * exp(-sigma_g(p)))`` over the Gaussians
-    binned to the pixel's tile; ``[H, W, 3]`` float32."""
-    if _USE_C and not return_alpha:
-        return _C.rasterize_gaussians_sum(xys, radii, conics, colors, opacity, img_height,
-                                          img_width, BLOCK_H, BLOCK_W, background)
+    binned to the pixel's tile; ``[H, W, D]`` float32.  The kernels render three channels per
+    colour set and up to three sets per launch: D = 3 (every call site of the reference) is one
+    launch; other D run ceil(D / 9) launches over zero-padded sets.  ``return_alpha=True`` adds
+    ``alpha[H, W]``, the accumulated weight ``sum_g min(cap, opacity[g] * exp(-sigma_g(p)))``
+    (the alpha of a sum has no transmittance meaning), from the same launch as the image."""
     if colors.ndimension() != 2:
         raise ValueError("colors must have dimensions (N, D)")
     if opacity.ndimension() != 2:
         raise ValueError("opacity must have dimensions (N, 1)")
-    if colors.shape[1] != 3:
-        raise ValueError("this build rasterizes 3 colour channels; got %d" % colors.shape[1])
+    if return_alpha or colors.shape[1] != 3:
+        return _rasterize_general(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
+                                  img_height, img_width, BLOCK_H, BLOCK_W, background, return_alpha)
+    if _USE_C:
+        return _C.rasterize_gaussians_sum(xys, radii, conics, colors, opacity, img_height,
+                                          img_width, BLOCK_H, BLOCK_W, background)
     if int(BLOCK_H) != BLOCK or int(BLOCK_W) != BLOCK:
         raise ValueError(f"tile size is fixed at {BLOCK}x{BLOCK} (the reference's train.py:54)")
     _need_cuda("rasterize_gaussians_sum", xys, conics, colors, opacity)
@@ -593,18 +598,37 @@ def rasterize_gaussians_sum(xys, depths, radii, conics, num_tiles_hit, colors, o
                     ("opacity", opacity)):
         if t.shape[0] != N:
             raise ValueError(f"{name} has {t.shape[0]} rows, xys has {N}")
-    out = _call(_RasterizeGaussiansSum, (xys, conics, colors, opacity), xys, depths, radii,
-                conics, num_tiles_hit, colors, opacity, int(img_height), int(img_width),
-                background)
+    return _call(_RasterizeGaussiansSum, (xys, conics, colors, opacity), xys, depths, radii,
+                 conics, num_tiles_hit, colors, opacity, int(img_height), int(img_width),
+                 background)
+
+
+def _rasterize_general(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                       img_width, BLOCK_H, BLOCK_W, background, return_alpha):
+    """Any number of channels, and the accumulated weight, through the multi-set rasteriser."""
+    N, D = colors.shape
+    if D < 1:
+        raise ValueError("colors must have at least one channel")
+    if background is None:
+        background = torch.ones(D, dtype=torch.float32, device=xys.device)
+    if background.shape[0] != D:
+        raise ValueError("background and colors must have the same number of channels")
+    padded = torch.nn.functional.pad(colors, (0, (-D) % 3)) if D % 3 else colors
+    sets = [padded[:, k:k + 3] for k in range(0, padded.shape[1], 3)]
     if return_alpha:
-        # never requested by the reference's 2D models; alpha of a sum has no transmittance
-        # meaning, so the accumulated weight of a white colour set is returned
-        ones = torch.ones_like(colors)
-        alpha = _RasterizeGaussiansSum.apply(xys.detach(), depths, radii, conics.detach(), 
-                                             num_tiles_hit, ones, opacity.detach(),
-                                             int(img_height), int(img_width), background)[..., 0]
-        return out, alpha
-    return out
+        sets.append(torch.ones(N, 3, dtype=torch.float32, device=colors.device))
+    # (the kernels add ONE 3-channel background to every set of a launch: it is added here)
+    no_bg = torch.zeros(3, dtype=torch.float32, device=xys.device)
+    outs = []
+    for k in range(0, len(sets), _lib.MAX_COLOR_SETS):
+        outs += list(rasterize_gaussians_sum_multi(
+            xys, depths, radii, conics, num_tiles_hit, sets[k:k + _lib.MAX_COLOR_SETS], opacity,
+            img_height, img_width, BLOCK_H, BLOCK_W, background=no_bg))
+    alpha = outs.pop()[..., 0] if return_alpha else None
+    img = outs[0] if D == 3 else torch.cat(outs, dim=-1)[..., :D]
+    if _CONV.bg_weight != 0.0:
+        img = img + _CONV.bg_weight * background.to(img.dtype)
+    return (img, alpha) if return_alpha else img
 
 
 def rasterize_gaussians_sum_multi(xys, depths, radii, conics, num_tiles_hit, colors, opacity,

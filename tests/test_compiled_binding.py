@@ -37,8 +37,9 @@ def test_compiled_binding_argument_errors_without_a_gpu():
         ops.rasterize_gaussians_sum(*args, torch.zeros(4), torch.zeros(4, 1), 32, 32, 16, 16)
     with pytest.raises(ValueError, match="opacity must have dimensions"):
         ops.rasterize_gaussians_sum(*args, L, torch.zeros(4), 32, 32, 16, 16)
-    with pytest.raises(ValueError, match="3 colour channels"):
-        ops.rasterize_gaussians_sum(*args, torch.zeros(4, 4), torch.zeros(4, 1), 32, 32, 16, 16)
+    with pytest.raises(ValueError, match="same number of channels"):
+        ops.rasterize_gaussians_sum(*args, torch.zeros(4, 4), torch.zeros(4, 1), 32, 32, 16, 16,
+                                    background=torch.ones(3))
     with pytest.raises(ValueError, match="tile size is fixed"):
         ops.rasterize_gaussians_sum(*args, L, torch.zeros(4, 1), 32, 32, 8, 8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -1234,3 +1234,78 @@ def test_late_overflow_report_does_not_stop_the_operators(ops, oracle):
                 torch.cuda.synchronize()
         assert 1 <= ws.late_overflows - before <= 2 and torch.isfinite(img).all()
         assert any("overflowed a tile list" in str(w.message) for w in caught)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compiled", [True, False])
+def test_other_channel_counts_and_the_accumulated_weight(compiled):
+    """colors[N, D] for D != 3 and return_alpha=True run through the multi-set rasteriser: every
+    channel is the bits of the same channel rendered in a 3-channel call, alpha is the bits of a
+    white colour set, the background is added per channel, and gradients reach colours and
+    geometry."""
+    from gaussianimage_amd import ops
+    H, W, N = 96, 128, 1500
+    means, L, col, op = synth.cholesky_inputs(N, seed=9)
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    prev = ops.use_compiled(compiled)
+    old = ops.get_conventions()["bg_weight"]
+    try:
+        with torch.no_grad():
+            proj = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+        g = torch.Generator().manual_seed(4)
+        wide = torch.rand(N, 7, generator=g).to(DEV)
+        opa = op.to(DEV)
+        zero = torch.zeros(3, device=DEV)
+
+        def three(c3):
+            return ops.rasterize_gaussians_sum(*proj, c3.contiguous(), opa, H, W, 16, 16,
+                                               background=zero)
+        for D in (1, 2, 5, 7):
+            img = ops.rasterize_gaussians_sum(*proj, wide[:, :D], opa, H, W, 16, 16,
+                                              background=torch.zeros(D, device=DEV))
+            assert img.shape == (H, W, D)
+            for ch in range(D):
+                base = 3 * (ch // 3)
+                c3 = torch.zeros(N, 3, device=DEV)
+                k = min(3, D - base)
+                c3[:, :k] = wide[:, base:base + k]
+                assert torch.equal(img[..., ch], three(c3)[..., ch - base]), (D, ch)
+        img, alpha = ops.rasterize_gaussians_sum(*proj, wide[:, :3].contiguous(), opa, H, W, 16, 16,
+                                                 background=zero, return_alpha=True)
+        assert torch.equal(img, three(wide[:, :3]))
+        assert alpha.shape == (H, W)
+        assert torch.equal(alpha, three(torch.ones(N, 3, device=DEV))[..., 0])
+        # the background enters once per channel and never the accumulated weight
+        ops.set_conventions(bg_weight=1.0)
+        bg = torch.tensor([0.1, 0.2, 0.3, 0.4, 0.5], device=DEV)
+        img5, alpha5 = ops.rasterize_gaussians_sum(*proj, wide[:, :5], opa, H, W, 16, 16,
+                                                   background=bg, return_alpha=True)
+        ops.set_conventions(bg_weight=0.0)
+        plain = ops.rasterize_gaussians_sum(*proj, wide[:, :5], opa, H, W, 16, 16,
+                                            background=bg)
+        assert torch.allclose(img5, plain + bg, atol=1e-6) and torch.equal(alpha5, alpha)
+        # gradients: five channels against the same loss written with two 3-channel calls
+        c5 = wide[:, :5].clone().requires_grad_(True)
+        xy = proj[0].clone().requires_grad_(True)
+        con = proj[3].clone().requires_grad_(True)
+        v = torch.randn(H, W, 5, generator=g).to(DEV)
+        out = ops.rasterize_gaussians_sum(xy, proj[1], proj[2], con, proj[4], c5, opa, H, W, 16, 16,
+                                          background=torch.zeros(5, device=DEV))
+        (out * v).sum().backward()
+        ca = wide[:, :3].clone().requires_grad_(True)
+        cb = torch.zeros(N, 3, device=DEV)
+        cb[:, :2] = wide[:, 3:5]
+        cb.requires_grad_(True)
+        xy2 = proj[0].clone().requires_grad_(True)
+        con2 = proj[3].clone().requires_grad_(True)
+        a = ops.rasterize_gaussians_sum(xy2, proj[1], proj[2], con2, proj[4], ca, opa, H, W, 16, 16,
+                                        background=zero)
+        b = ops.rasterize_gaussians_sum(xy2, proj[1], proj[2], con2, proj[4], cb, opa, H, W, 16, 16,
+                                        background=zero)
+        ((a * v[..., :3]).sum() + (b[..., :2] * v[..., 3:]).sum()).backward()
+        assert torch.equal(c5.grad[:, :3], ca.grad) and torch.equal(c5.grad[:, 3:], cb.grad[:, :2])
+        assert torch.allclose(xy.grad, xy2.grad, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(con.grad, con2.grad, rtol=1e-5, atol=1e-6)
+    finally:
+        ops.set_conventions(bg_weight=old)
+        ops.use_compiled(prev)
