@@ -4,8 +4,9 @@ C ABI, on synthetic parameters with the reference models' own initial distributi
 
     python bench.py --gpus N --steps K --warmup W [--workload NAME] [--batch B]
 
-One "step" is one pass of the hot path over one BATCH of B independent frames (default 8, each
-with its own Gaussians) whose operator inputs are already resident in HBM: one C call
+One "step" is one pass of the hot path over one BATCH of B independent frames (default 24 -- the
+size of the Kodak set the reference loops over, /root/reference/train.py:358-366 -- each with
+its own Gaussians) whose operator inputs are already resident in HBM: one C call
 (gi2d_render_batch), two launches.  N=1 runs BASELINE config 2 (768x512, 30k Gaussians,
 Cholesky).  `value` is frames per second.  The timed region is EXACTLY K steps between
 synchronisations; because K steps of this path last only about a millisecond, that region is
@@ -603,7 +604,7 @@ def secondary(args, device, batch, run, batch_in, B, I_8d, I_held, raster_batch_
             ex["fps_batches_in_flight_%d" % depth] = B * 1e3 / ms
             del ring
         sweep = {}
-        for b in (1, 2, 4, 16):   # the headline call at other batch sizes
+        for b in (1, 2, 4, 8, 16, 32):   # the headline call at other batch sizes
             fb, frun = bound_batch(args.workload, device, b)
             sweep[str(b)] = b * 1e3 / bench_region(frun, 60, 10)
             del fb, frun
@@ -691,7 +692,9 @@ def main():
     no_gc().__enter__()
     H, W, N, kind, fp = WORKLOADS[args.workload]
     P, T = H * W, tiles_of(H, W)
-    B = args.batch or (8 if T < 20000 else 1)
+    # frames per step: the 24 images of the Kodak set (/root/reference/train.py:358-359) for the
+    # small frames; a 3840x2160 frame fills the chip alone
+    B = args.batch or (24 if T < 20000 else 1)
     batch_in = make_batch_inputs(args.workload, device, B, seed=1 + rank * B)
     batch = FrameBatch(B, N, H, W, kind=kind, device=device)
     if args.raster_ppl:

@@ -26,5 +26,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d $O -o pmc_SQ -- python3 $R/bench.py $HEAD > $O/pmc_SQ.log 2>&1 || { tail -20 $O/pmc_SQ.log; exit 1; }
 cd $R
-python3 tools/counters_json.py $O kodak30k_batch8 "tools/gpu_profiles_r02.sh: rocprofv3 --pmc passes of 'bench.py $HEAD'"
+python3 tools/counters_json.py $O kodak30k_batch24 "tools/gpu_profiles_r02.sh: rocprofv3 --pmc passes of 'bench.py $HEAD'"
 ls $O | head -40
