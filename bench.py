@@ -653,6 +653,9 @@ def main():
                          "a second workload blur a profiler's per-kernel averages)")
     ap.add_argument("--raster-ppl", type=int, default=0, choices=[0, 1, 2, 4],
                     help="pixels per lane of the forward rasteriser (0 = the library's choice)")
+    ap.add_argument("--project-form", type=int, default=0,
+                    help="how the projection fills the lists (GI2D_OPT_PROJECT_AGG; 0 = the "
+                         "library's choice)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="steps in flight: consecutive steps alternate between this many batch "
                          "objects, each on a stream of its own")
@@ -699,6 +702,10 @@ def main():
     batch = FrameBatch(B, N, H, W, kind=kind, device=device)
     if args.raster_ppl:
         batch.ws.set_raster_ppl(args.raster_ppl)
+    if args.project_form:
+        from gaussianimage_amd import _lib
+        _lib.check(_lib.lib.gi2d_workspace_set_option(batch.ws.handle, _lib.OPT_PROJECT_AGG,
+                                                      args.project_form), "set_option")
     run = batch.bind(*batch_in)
     run()
     run()
