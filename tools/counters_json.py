@@ -8,6 +8,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -21,16 +22,17 @@ for path in glob.glob(os.path.join(root, "**", "pmc_*_counter_collection.csv"), 
 def avg(kernel_part, counter, skip_first=2):
     vals = []
     for k, d in acc.items():
-        if kernel_part in k and counter in d:
+        if re.search(kernel_part, k) and counter in d:
             vals += d[counter]
     vals = vals[skip_first:] if len(vals) > skip_first + 4 else vals
     return sum(vals) / len(vals) if vals else None
 
 
 out = {"source": source}
-for tag, part in (("raster_fwd", "rasterize_sum_fwd_kernel<true, false, 1, 1, true>"),
-                  ("project", "project_agg_fwd_kernel<false>"),
-                  ("project_direct", "project_cholesky_fwd_kernel<false>")):
+# (the batch launch's rasteriser: first pass, one colour set, records; any workgroup shape)
+for tag, part in (("raster_fwd", r"rasterize_sum_fwd_kernel<true, false, 1, \d, true>"),
+                  ("project", r"project_agg_fwd_kernel<false>"),
+                  ("project_direct", r"project_cholesky_fwd_kernel<false>")):
     f, w = avg(part, "FETCH_SIZE"), avg(part, "WRITE_SIZE")
     if f is not None and w is not None:
         out[tag + "_fetch_bytes_x2"] = f * 1024 * 2
