@@ -575,6 +575,20 @@ def secondary(args, device, batch, run, batch_in, B, I_8d, I_held, raster_batch_
                              "bytes / step time"},
         "fwd_bwd_roofline_frac": (b_fwd + b_bwd) / (fwd_bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
+    if T < 20000:
+        # the same fused iteration for a batch of images fitted in lockstep (one call, three
+        # launches: batch projection, fused rasterisation, tail): the images of a dataset
+        from gaussianimage_amd._testing import synth
+        from gaussianimage_amd.fit import BatchFitter
+        gts = torch.stack([synth.target_image(H, W, seed=f)[0] for f in range(B)]).to(
+            device).contiguous()
+        bfit = BatchFitter(B, N, H, W, kind=kind, device=device)
+        bms = bench_region(lambda: bfit.step(gts), max(20, k // 2), 10)
+        out["train_step"]["fused_batch"] = {
+            "images": B, "ms_per_step": bms, "ms_per_image_iteration": bms / B,
+            "image_iterations_per_s": B * 1e3 / bms,
+            "roofline_frac": (b_fwd + b_bwd + b_adan) * B / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del bfit, gts
     out["kernels"] = kernels
 
     # ---- extras -------------------------------------------------------------------------------

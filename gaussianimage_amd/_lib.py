@@ -114,6 +114,8 @@ SIGNATURES = {
                                           ctypes.POINTER(AdanHyper), _vp]),
     "gi2d_fit_step": (_i, [_vp, _i] + [_vp] * 7 + [_i, _i, _i, _convp] + [_vp] * 11 +
                       [ctypes.POINTER(AdanHyper), _vp]),
+    "gi2d_fit_step_batch": (_i, [_vp, _i, _i] + [_vp] * 7 + [_i, _i, _i, _convp] + [_vp] * 11 +
+                            [ctypes.POINTER(AdanHyper), _vp]),
     "gi2d_fit_raster": (_i, [_vp, _i] + [_vp] * 7 + [_i, _i, _i, _convp] + [_vp] * 11 + [_vp]),
     "gi2d_fit_tail": (_i, [_vp, _i] + [_vp] * 5 + [_i, _i, _i, _convp] + [_vp] * 12 +
                       [ctypes.POINTER(AdanHyper), _vp]),

@@ -36,6 +36,10 @@ struct GradIn {
 // CHAIN = true: having updated Gaussian g's parameters, the lane goes straight on to the next
 // iteration's projection of g (model activations included) -- outputs overwritten in place,
 // tile lists of the next frame filled -- so the next iteration needs no projection launch.
+//
+// gridDim.y = the images of a batch that is fitted in lockstep: image f has Gaussians
+// [f*N, (f+1)*N) of every parameter, state and per-Gaussian tensor and its own run of tile lists;
+// ids in the lists are image-local.
 template <bool RS, bool CHAIN, bool GRADS>
 __global__ __launch_bounds__(256) void fit_tail_kernel(
     AdanTensors T, AdanScalars h, float *xys, int *radii, int N, int H, int W, int tiles_x,
@@ -44,8 +48,47 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
     const float *__restrict__ gslots, size_t gslot_n, int stamp, ChainArgs ch, GradIn gin)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (CHAIN && g == 0) publish_status(ch.status, ch.h_status, ch.generation);
+    const int f = blockIdx.y;
+    if (CHAIN && g == 0 && f == 0) publish_status(ch.status, ch.h_status, ch.generation);
     if (g >= N) return;
+    if (f != 0) {
+        const size_t n = (size_t)f * N, t = (size_t)f * tiles_x * (row1 - row0);
+        const size_t dims[4] = {2, RS ? 2 : 3, 1, 3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t o = n * dims[k];
+            T.p[k] += o;
+            T.m[k] += o;
+            T.n[k] += o;
+            T.d[k] += o;
+            T.prev[k] += o;
+        }
+        xys += 2 * n;
+        radii += n;
+        tile_len += t;
+        seg += t * C;
+        partials += t * C * PART_STRIDE;
+        gslots += n * GSLOT_STRIDE;
+        if (GRADS) {
+            gin.v_xy += 2 * n;
+            gin.v_conic += 3 * n;
+            gin.v_colors += 3 * n;
+        }
+        if (CHAIN) {
+            ch.out.xys += 2 * n;
+            ch.out.depths += n;
+            ch.out.radii += n;
+            ch.out.conics += 3 * n;
+            ch.out.num_tiles_hit += n;
+            ch.lists.tile_count += t * CNT_STRIDE;
+            ch.lists.seg += t * ch.lists.C;
+            if (ch.cull.opacity != nullptr) ch.cull.opacity += n;
+            if (ch.rec.rec != nullptr) {
+                ch.rec.rec += n * REC_FLOATS;
+                ch.rec.opacity += n;
+            }
+        }
+    }
     // Parameters, optimizer state and the Gaussian's own partial-sum slots depend on nothing but
     // g: one round trip for all of them.
     const size_t g2 = 2 * (size_t)g, g3 = 3 * (size_t)g;
@@ -231,9 +274,26 @@ fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *
                   DevStatus *status,
                   long long generation, float *__restrict__ out, const float *__restrict__ gt,
                   float *__restrict__ loss_part, float *__restrict__ partials,
-                  float *__restrict__ gslots, size_t gslot_n, int stamp)
+                  float *__restrict__ gslots, size_t gslot_n, int stamp, int N)
 {
     static_assert(PPL == 1 || PPL == 4, "unsupported variant");
+    if (blockIdx.y != 0) {  // image f of a batch (see fit_tail_kernel)
+        const size_t n = (size_t)blockIdx.y * N, t = (size_t)blockIdx.y * T;
+        tile_count += t * CNT_STRIDE;
+        tile_len += t;
+        seg += t * C;
+        xys += 2 * n;
+        radii += n;
+        conics += 3 * n;
+        colors += 3 * n;
+        opacity += n;
+        rec += n * REC_FLOATS;
+        if (out != nullptr) out += (size_t)blockIdx.y * H * W * 3;
+        gt += (size_t)blockIdx.y * H * W * 3;
+        loss_part += t;
+        partials += t * C * PART_STRIDE;
+        gslots += n * GSLOT_STRIDE;
+    }
     constexpr int NT = 256 / PPL;
     constexpr int FWD_INTS = FWD_LDS_INTS_PER_ENTRY * NT;
     // LDS the two phases use one after the other (forward staging records, then the backward's
@@ -356,21 +416,23 @@ static int fit_project_bin(gi2d_workspace *ws, int kind, const float *xyz, const
                            const float *cov_b, const float *features, const float *opacity, int N,
                            int H, int W,
                            const gi2d_conv *conv, float *xys, float *depths, int *radii,
-                           float *conics, int *num_tiles_hit, void *stream)
+                           float *conics, int *num_tiles_hit, void *stream, int frames = 1)
 {
     const int tiles_x = cdiv(W, GI2D_BLOCK), tiles_y = cdiv(H, GI2D_BLOCK);
     const bool chained = ws->chain_pending && ws->prefilled && ws->chain_kind == kind &&
                          ws->chain_xys == (const void *)xys && ws->pre_n == N &&
-                         ws->pre_tx == tiles_x && ws->pre_ty == tiles_y;
+                         ws->pre_tx == tiles_x && ws->pre_ty == tiles_y &&
+                         ws->pre_frames == frames;
     if (!chained) {
         ProjExtras ex;
         ex.opacity = opacity;
         ex.colors = features;
+        ex.frames = frames;
         int rc = project_impl(kind, true, xyz, cov_a, cov_b, N, H, W, tiles_x, tiles_y, conv, xys,
                               depths, radii, conics, num_tiles_hit, ws, stream, ex);
         if (rc != GI2D_OK) return rc;
     }
-    return gi2d_bin_tiles(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream);
+    return bin_tiles_impl(ws, xys, radii, N, tiles_x, tiles_y, GI2D_BIN_COUNTED, stream, frames);
 }
 
 extern "C" {
@@ -406,10 +468,12 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
                              float *const *exp_avg_sq, float *const *exp_avg_diff,
                              float *const *neg_pre_grad, const gi2d_adan_hyper *hyper,
                              void *stream, const ChainOutputs *chain, bool pass1_done = false,
-                             const GradIn *grads = nullptr)
+                             const GradIn *grads = nullptr, int frames = 1)
 {
     if (kind != 0 && kind != 1) return GI2D_E_INVALID;
-    int rc = check_raster_args(ws, N, H, W, conv);
+    // (several images only through the fused rasterisation kernel, which has done pass 1)
+    if (frames < 1 || (frames > 1 && (!pass1_done || grads))) return GI2D_E_INVALID;
+    int rc = check_raster_args(ws, N, H, W, conv, frames);
     if (rc != GI2D_OK) return rc;
     AdanScalars h;
     rc = adan_scalars(hyper, h);
@@ -442,8 +506,13 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
                               st);
         if (rc != GI2D_OK) return rc;
     }
-    bool chained = chain != nullptr && begin_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y);
-    if (chained && !ws->no_records && ensure_records(ws, N) != GI2D_OK) {
+    // (a batch of four images and more projects with its own launch instead: the chained lanes
+    // fill the lists with one counter atomic per (Gaussian, tile) pair, the batch projection
+    // aggregates them in LDS, and the part's rate of returning atomics is what a chained tail
+    // of 24 images would wait for)
+    bool chained = chain != nullptr && frames < 4 &&
+                   begin_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y, frames);
+    if (chained && !ws->no_records && ensure_records(ws, (int64_t)frames * N) != GI2D_OK) {
         (void)hipGetLastError();
         chained = false;
     }
@@ -471,7 +540,7 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
     // one wave per workgroup when the lanes also issue the list-filling atomics, so that the
     // launch spreads over every CU (as in the projection kernels)
     const int threads = chained ? PG_THREADS : 256;
-    const dim3 grid(cdiv(N, threads)), block(threads);
+    const dim3 grid(cdiv(N, threads), frames), block(threads);
     {
     Probe probe(ws, GI2D_PROBE_FIT_TAIL, st);
 #define GI2D_TAIL(RS, GR)                                                                   \
@@ -488,7 +557,7 @@ static int fit_backward_impl(gi2d_workspace *ws, int kind, float *xyz, float *co
 #undef GI2D_TAIL_ARGS
     rc = launch_status();
     if (rc == GI2D_OK && chained) {
-        commit_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y, kind, chain->xys);
+        commit_chain_prefill(ws, N, ws->tiles_x, ws->tiles_y, kind, chain->xys, frames);
         // the records the tail wrote are the next frame's, for these tensors
         ws->rec_valid = ch.rec.rec != nullptr;
         ws->rec_xys = chain->xys;
@@ -533,19 +602,20 @@ static int fit_raster_impl(gi2d_workspace *ws, int kind, const float *xyz, const
                            const float *background, const float *gt_chw, int N, int H, int W,
                            const gi2d_conv *conv, float *xys, float *depths, int *radii,
                            float *conics, int *num_tiles_hit, float *image, float *loss_partials,
-                           void *stream, int *late_out, bool *ran)
+                           void *stream, int *late_out, bool *ran, int frames = 1)
 {
     *ran = false;
+    if (frames < 1) return GI2D_E_INVALID;
     if (!ws || (kind != 0 && kind != 1) || !gt_chw || !loss_partials) return GI2D_E_INVALID;
     if (N > 0 && (!xys || !depths || !radii || !conics || !num_tiles_hit)) return GI2D_E_INVALID;
     if (N > 0 && (!xyz || !cov_a || (kind == 1 && !cov_b) || !features || !opacity))
         return GI2D_E_INVALID;
     if (conv && conv->bg_weight != 0.0f && !background) return GI2D_E_INVALID;
     int rc = fit_project_bin(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
-                             depths, radii, conics, num_tiles_hit, stream);
+                             depths, radii, conics, num_tiles_hit, stream, frames);
     if (rc != GI2D_OK && rc != GI2D_E_PREV_OVERFLOW) return rc;
     *late_out = rc;
-    rc = check_raster_args(ws, N, H, W, conv);
+    rc = check_raster_args(ws, N, H, W, conv, frames);
     if (rc != GI2D_OK) return rc;
     const int T = ws->tiles_x * (ws->bin_row1 - ws->bin_row0);
     if (T == 0) {  // empty band
@@ -554,7 +624,8 @@ static int fit_raster_impl(gi2d_workspace *ws, int kind, const float *xyz, const
     }
     DeviceGuard guard(ws->device);
     hipStream_t st = (hipStream_t)stream;
-    rc = ensure_bwd_buffers(ws, N);
+    if ((int64_t)frames * N >= (int64_t)INT_MAX / 16) return GI2D_E_INVALID;
+    rc = ensure_bwd_buffers(ws, frames * N);
     if (rc != GI2D_OK) return rc;
     rc = next_bwd_stamp(ws, st);
     if (rc != GI2D_OK) return rc;
@@ -566,12 +637,18 @@ static int fit_raster_impl(gi2d_workspace *ws, int kind, const float *xyz, const
                              ws->tiles_y,                                                        \
                              ws->bin_row0, T, *conv, ws->cull, ws->d_status, ws->generation,     \
                              image, gt_chw, loss_partials, ws->d_partials, ws->d_gslots,         \
-                             (size_t)ws->slot_cap, ws->bwd_stamp
-    const bool one_wave = sparse_frame(ws, T);
-#define GI2D_FIT_RASTER(FIN, PK)                                                         \
-    do {                                                                                 \
-        if (one_wave) fit_raster_kernel<FIN, 4, PK><<<T, 64, 0, st>>>(GI2D_FIT_RASTER_ARGS); \
-        else fit_raster_kernel<FIN, 1, PK><<<T, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);         \
+                             (size_t)ws->slot_cap, ws->bwd_stamp, N
+    // (a launch of many tiles: one wave per tile, as in the forward rasteriser -- unless the
+    // lists are long, which the one-wave backward walks without its work-piece path)
+    const bool one_wave =
+        frames > 1 && ws->raster_ppl == 0
+            ? (long long)T * frames >= GI2D_PPL4_MIN_TILES && ws->h_status[0] <= 128
+            : sparse_frame(ws, T);
+    const dim3 grid(T, frames);
+#define GI2D_FIT_RASTER(FIN, PK)                                                            \
+    do {                                                                                    \
+        if (one_wave) fit_raster_kernel<FIN, 4, PK><<<grid, 64, 0, st>>>(GI2D_FIT_RASTER_ARGS); \
+        else fit_raster_kernel<FIN, 1, PK><<<grid, 256, 0, st>>>(GI2D_FIT_RASTER_ARGS);         \
     } while (0)
     {
     Probe probe(ws, GI2D_PROBE_FIT_RASTER, st);
@@ -611,6 +688,30 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
     rc = fit_backward_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
                            radii, conics, nullptr, exp_avg, exp_avg_sq, exp_avg_diff, neg_pre_grad,
                            hyper, stream, &chain, true);
+    return rc != GI2D_OK ? rc : late;
+}
+
+int gi2d_fit_step_batch(gi2d_workspace *ws, int kind, int frames, float *xyz, float *cov_a,
+                        float *cov_b, float *features, const float *opacity,
+                        const float *background, const float *gt_chw, int N, int H, int W,
+                        const gi2d_conv *conv, float *xys, float *depths, int *radii,
+                        float *conics, int *num_tiles_hit, float *images, float *loss_partials,
+                        float *const *exp_avg, float *const *exp_avg_sq,
+                        float *const *exp_avg_diff, float *const *neg_pre_grad,
+                        const gi2d_adan_hyper *hyper, void *stream)
+{
+    if (!hyper || hyper->step < 1 || frames < 1) return GI2D_E_INVALID;
+    int late = GI2D_OK;
+    bool ran = false;
+    int rc = fit_raster_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, background, gt_chw, N,
+                             H, W, conv, xys, depths, radii, conics, num_tiles_hit, images,
+                             loss_partials, stream, &late, &ran, frames);
+    if (rc != GI2D_OK) return rc;
+    if (!ran) return late;
+    const ChainOutputs chain = {xys, depths, conics, radii, num_tiles_hit};
+    rc = fit_backward_impl(ws, kind, xyz, cov_a, cov_b, features, opacity, N, H, W, conv, xys,
+                           radii, conics, nullptr, exp_avg, exp_avg_sq, exp_avg_diff, neg_pre_grad,
+                           hyper, stream, &chain, true, nullptr, frames);
     return rc != GI2D_OK ? rc : late;
 }
 

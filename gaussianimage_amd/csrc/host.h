@@ -152,9 +152,9 @@ int wanted_cap(const gi2d_workspace *ws, long long seen);
 int zero_counters(gi2d_workspace *ws, hipStream_t st);
 int finalize_lists(gi2d_workspace *ws, hipStream_t st);
 int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int frames, hipStream_t st);
-bool begin_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y);
+bool begin_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int frames = 1);
 void commit_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int kind,
-                          const void *xys);
+                          const void *xys, int frames = 1);
 
 // project.hip
 // Optional parts of a projection call.  codec: the inputs are coded attributes (means / cov_a /

@@ -234,10 +234,10 @@ int begin_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int frame
 // being read.  Possible when the current lists are finalised and valid, the shape is unchanged
 // and no capacity growth is due (a growth reallocates, which would lose the current lists: the
 // next projection does it instead).  Makes sure the second list set exists; the device is current.
-bool begin_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y)
+bool begin_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int frames)
 {
     const int r0 = min(ws->row0, tiles_y), r1 = min(ws->row1, tiles_y);
-    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1)) return false;  // (one frame)
+    if (shape_is_new(ws, N, tiles_x, tiles_y, r0, r1, frames)) return false;
     if (ws->counters_dirty || ws->lists_raw || !ws->lists_valid || ws->seg_cap == 0) return false;
     if (wanted_cap(ws, ws->h_status[0]) > ws->seg_cap) return false;
     if (!ws->alt_count) {
@@ -260,7 +260,7 @@ bool begin_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y)
 // The chained fill has been launched into the second set: it becomes the current one, in the
 // state a projection with list filling leaves behind (gi2d_bin_tiles(COUNTED) picks it up).
 void commit_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int kind,
-                          const void *xys)
+                          const void *xys, int frames)
 {
     int *t;
     t = ws->d_count, ws->d_count = ws->alt_count, ws->alt_count = t;
@@ -275,7 +275,7 @@ void commit_chain_prefill(gi2d_workspace *ws, int N, int tiles_x, int tiles_y, i
     ws->pre_ty = tiles_y;
     ws->pre_r0 = min(ws->row0, tiles_y);
     ws->pre_r1 = min(ws->row1, tiles_y);
-    ws->pre_frames = 1;
+    ws->pre_frames = frames;
     ws->chain_pending = true;
     ws->chain_kind = kind;
     ws->chain_xys = xys;

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
 #define AGG_ROUNDS 8
 #define AGG_MAX_TILES 4096
 
-template <bool RS>
+// RAW: the model's raw parameters, activated here (as in project_*_fwd_kernel<RAW>).
+template <bool RS, bool RAW>
 __global__ __launch_bounds__(AGG_THREADS) void project_agg_fwd_kernel(
     const float *__restrict__ means, const float *__restrict__ cov_a,
     const float *__restrict__ cov_b, ProjArgs a, int chunk)
@@ -184,18 +185,32 @@ __global__ __launch_bounds__(AGG_THREADS) void project_agg_fwd_kernel(
         boxes[r] = 0;
         const int g = g0 + r * AGG_THREADS + tid;
         if (g < g1) {
-            const float mx = means[2 * g], my = means[2 * g + 1];
+            float mx = means[2 * g], my = means[2 * g + 1];
+            if (RAW) {
+                mx = tanhf(mx);
+                my = tanhf(my);
+            }
             float sxx, sxy, syy;
             if (RS) {
+                float theta = cov_b[g];
+                float s1 = cov_a[2 * g], s2 = cov_a[2 * g + 1];
+                if (RAW) {
+                    s1 = fabsf(s1 + 0.5f);
+                    s2 = fabsf(s2 + 0.5f);
+                    theta = (1.0f / (1.0f + expf(-theta))) * 2.0f * 3.14159274f;
+                }
                 float s, c;
-                gi2d_sincos_f32(cov_b[g], &s, &c);
-                const float s1 = cov_a[2 * g], s2 = cov_a[2 * g + 1];
+                gi2d_sincos_f32(theta, &s, &c);
                 const float q1 = s1 * s1, q2 = s2 * s2;
                 sxx = c * c * q1 + s * s * q2;
                 sxy = c * s * (q1 - q2);
                 syy = s * s * q1 + c * c * q2;
             } else {
-                const float l11 = cov_a[3 * g], l21 = cov_a[3 * g + 1], l22 = cov_a[3 * g + 2];
+                float l11 = cov_a[3 * g], l21 = cov_a[3 * g + 1], l22 = cov_a[3 * g + 2];
+                if (RAW) {
+                    l11 = l11 + 0.5f;
+                    l22 = l22 + 0.5f;
+                }
                 sxx = l11 * l11;
                 sxy = l11 * l21;
                 syy = l21 * l21 + l22 * l22;
@@ -620,14 +635,14 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
     const dim3 grid(cdiv(N, PG_THREADS), frames), block(PG_THREADS);
     // The LDS-aggregated list filling pays when its few large workgroups still fill the chip:
     // batches.  One frame keeps the direct kernels (GI2D_OPT_PROJECT_AGG forces either form).
-    const bool whole = fill && !codec && !raw && tiles_x < 256 && tiles_y < 256 &&
-                       ws->pre_r0 == 0 && ws->pre_r1 == tiles_y;
+    const bool whole = fill && !codec && tiles_x < 256 && tiles_y < 256 && ws->pre_r0 == 0 &&
+                       ws->pre_r1 == tiles_y;
     bool agg = whole && a.tiles_per_frame <= AGG_MAX_TILES;
     // bands: enough of them to fill the chip, each within the LDS counters; every workgroup
     // scans all N boxes of its frame, which bounds N
     int bands = whole ? max(1, min(tiles_y, 256 / frames)) : 0;
     int rows_per_band = whole ? cdiv(tiles_y, bands) : 0;
-    bool by_bands = whole && rows_per_band * tiles_x <= AGG_MAX_TILES &&
+    bool by_bands = whole && !raw && rows_per_band * tiles_x <= AGG_MAX_TILES &&
                     N <= BAND_MAX_ROUNDS * AGG_THREADS;
     // (on request only: at 8 x 30 000 Gaussians its two launches take 11 + 13 us against 19.8 us
     // for the aggregated form -- the scan of all boxes by every band is a chain of memory rounds)
@@ -653,10 +668,13 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
         per_frame = max(per_frame, cdiv(N, AGG_THREADS * AGG_ROUNDS));
         const int chunk = cdiv(N, per_frame);
         const dim3 agrid(cdiv(N, chunk), frames);
-        if (kind == 0)
-            project_agg_fwd_kernel<false><<<agrid, AGG_THREADS, 0, st>>>(means, cov_a, cov_b, a, chunk);
-        else
-            project_agg_fwd_kernel<true><<<agrid, AGG_THREADS, 0, st>>>(means, cov_a, cov_b, a, chunk);
+#define GI2D_AGG(RS, RAW) \
+    project_agg_fwd_kernel<RS, RAW><<<agrid, AGG_THREADS, 0, st>>>(means, cov_a, cov_b, a, chunk)
+        if (kind == 0 && raw) GI2D_AGG(false, true);
+        else if (kind == 0) GI2D_AGG(false, false);
+        else if (raw) GI2D_AGG(true, true);
+        else GI2D_AGG(true, false);
+#undef GI2D_AGG
     } else if (codec) {
         if (kind == 0)
             project_decode_fwd_kernel<false><<<grid, block, 0, st>>>(*codec, ex.colors_out, a);

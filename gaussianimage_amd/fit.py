@@ -21,7 +21,7 @@ from . import _lib
 from ._lib import BLOCK, check, lib
 from .ops import Workspace, _ptr, _stream, get_conventions
 
-__all__ = ["FusedFitter"]
+__all__ = ["FusedFitter", "BatchFitter"]
 
 
 class FusedFitter:
@@ -199,4 +199,117 @@ class FusedFitter:
     def state_dict(self):
         sd = {k: v.clone() for k, v in self.params.items()}
         sd["_opacity"] = self._opacity.clone()
+        return sd
+
+
+class BatchFitter:
+    """``frames`` images of one size fitted in lockstep by ``gi2d_fit_step_batch``: the fused
+    iteration of ``FusedFitter`` over all of them in the same two launches.  Parameters, optimizer
+    state and outputs are ``[frames, N, ...]`` tensors (``params["_xyz"][f]`` is image f's
+    ``_xyz``); targets are one contiguous ``[frames, 3, H, W]`` tensor.  Image f follows, bit for
+    bit, the trajectory ``FusedFitter`` gives it alone.  For the reference's loop over the images
+    of a dataset (/root/reference/train.py:366-372), where one 768x512 fit leaves most of the
+    chip idle.
+    """
+
+    def __init__(self, frames, num_points, H, W, kind="cholesky", device="cuda:0", lr=1e-3,
+                 betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.0, no_prox=False,
+                 lr_step=20000, lr_gamma=0.5, params=None, keep_images=False):
+        if kind not in ("cholesky", "rs"):
+            raise ValueError("kind must be 'cholesky' or 'rs'")
+        if frames < 1:
+            raise ValueError("frames >= 1 required")
+        self.kind, self.F, self.N = kind, int(frames), int(num_points)
+        self.H, self.W = int(H), int(W)
+        self.device = torch.device(device)
+        self.lr0, self.betas, self.eps = lr, betas, eps
+        self.weight_decay, self.no_prox = weight_decay, no_prox
+        self.lr_step, self.lr_gamma = lr_step, lr_gamma
+        F, N, d, f32, i32 = self.F, self.N, self.device, torch.float32, torch.int32
+        names = (["_xyz", "_cholesky", None, "_features_dc"] if kind == "cholesky" else
+                 ["_xyz", "_scaling", "_rotation", "_features_dc"])
+        dims = {"_xyz": 2, "_cholesky": 3, "_scaling": 2, "_rotation": 1, "_features_dc": 3}
+        if params is None:  # the reference's initial distributions, image by image
+            params = {k: (torch.atanh(2 * (torch.rand(F, N, 2) - 0.5)) if k == "_xyz"
+                          else torch.rand(F, N, dims[k])) for k in names if k}
+        self.names = names
+        self.params = {}
+        for k in names:
+            if k:
+                p = params[k].detach().to(d, f32).contiguous().clone()
+                if tuple(p.shape) != (F, N, dims[k]):
+                    raise ValueError(f"{k} must have shape {(F, N, dims[k])}")
+                self.params[k] = p
+        self._opacity = torch.ones(F, N, 1, dtype=f32, device=d)
+        self.background = torch.ones(3, dtype=f32, device=d)
+        self.state = {k: {s: torch.zeros_like(p) for s in
+                          ("exp_avg", "exp_avg_sq", "exp_avg_diff", "neg_pre_grad")}
+                      for k, p in self.params.items()}
+        self.step_count = 0
+        self.overflowed_frames = 0
+        self.ws = Workspace(d)
+        self.conv = _lib.default_conv(**get_conventions())
+        self.tiles = ((W + BLOCK - 1) // BLOCK) * ((H + BLOCK - 1) // BLOCK)
+        self.xys = torch.empty(F, N, 2, dtype=f32, device=d)
+        self.depths = torch.empty(F, N, dtype=f32, device=d)
+        self.radii = torch.empty(F, N, dtype=i32, device=d)
+        self.conics = torch.empty(F, N, 3, dtype=f32, device=d)
+        self.num_tiles_hit = torch.empty(F, N, dtype=i32, device=d)
+        self.images = torch.empty(F, H, W, 3, dtype=f32, device=d) if keep_images else None
+        self.loss_partials = torch.zeros(F, self.tiles, dtype=f32, device=d)
+        self._versions = None
+        p = [self.params[k] if k else None for k in names]
+        arr = lambda key: (ctypes.c_void_p * 4)(*[  # noqa: E731
+            self.state[k][key].data_ptr() if k else None for k in names])
+        self._state_arrays = tuple(arr(k) for k in
+                                   ("exp_avg", "exp_avg_sq", "exp_avg_diff", "neg_pre_grad"))
+        self._head = (self.ws.handle, 0 if kind == "cholesky" else 1, F, _ptr(p[0]), _ptr(p[1]),
+                      _ptr(p[2]), _ptr(p[3]), _ptr(self._opacity), _ptr(self.background))
+        self._tail = (N, self.H, self.W, ctypes.byref(self.conv), _ptr(self.xys),
+                      _ptr(self.depths), _ptr(self.radii), _ptr(self.conics),
+                      _ptr(self.num_tiles_hit), _ptr(self.images), _ptr(self.loss_partials),
+                      *self._state_arrays)
+        self._stream = _stream(self.device)
+
+    @property
+    def lr(self):
+        return self.lr0 * self.lr_gamma ** (self.step_count // self.lr_step)
+
+    def step(self, gt_images):
+        """One fitting iteration of every image; ``gt_images``: contiguous float32
+        ``[frames, 3, H, W]`` on the device.  No host synchronisation."""
+        if gt_images.device != self.device or gt_images.dtype != torch.float32 or \
+                not gt_images.is_contiguous() or \
+                gt_images.numel() != self.F * 3 * self.H * self.W:
+            raise ValueError("gt_images must be a contiguous float32 [frames,3,H,W] tensor on "
+                             "the device")
+        versions = tuple(p._version for p in self.params.values())
+        if self._versions is not None and self._versions != versions:
+            # someone else wrote the parameters since the chained step projected them
+            check(lib.gi2d_workspace_set_option(self.ws.handle, _lib.OPT_DROP_PENDING, 1),
+                  "gi2d_workspace_set_option")
+        b1, b2, b3 = self.betas
+        lr = self.lr
+        self.step_count += 1
+        hyper = _lib.AdanHyper(lr, b1, b2, b3, self.eps, self.weight_decay,
+                               int(bool(self.no_prox)), self.step_count)
+        rc = lib.gi2d_fit_step_batch(*self._head, _ptr(gt_images), *self._tail,
+                                     ctypes.byref(hyper), self._stream)
+        self._versions = tuple(p._version for p in self.params.values())
+        if rc == _lib.GI2D_E_PREV_OVERFLOW:   # (see FusedFitter._late_overflow)
+            self.overflowed_frames += 1
+            rc = 0
+        check(rc, "gi2d_fit_step_batch")
+
+    def losses(self):
+        """Mean squared error of every image in the last step's forward (synchronises)."""
+        return (self.loss_partials.double().sum(dim=1) / (3 * self.H * self.W)).cpu()
+
+    def psnrs(self):
+        return [10 * math.log10(1.0 / max(float(v), 1e-30)) for v in self.losses()]
+
+    def state_dict(self, frame):
+        """Image ``frame``'s parameters under the reference model's names."""
+        sd = {k: v[frame].clone() for k, v in self.params.items()}
+        sd["_opacity"] = self._opacity[frame].clone()
         return sd

@@ -354,6 +354,23 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
                   float *const *exp_avg_diff, float *const *neg_pre_grad,
                   const gi2d_adan_hyper *hyper, void *stream);
 
+/* gi2d_fit_step for `frames` images of one size fitted in lockstep -- the same iteration number,
+ * learning rate and N Gaussians each -- in the same TWO launches: every parameter, optimizer-state
+ * and per-Gaussian tensor is [frames][N][...] (the four state arrays hold one pointer per
+ * parameter tensor, as in gi2d_fit_step), gt_chw is [frames][3][H][W], images (optional)
+ * [frames][H][W][3], loss_partials [frames][tiles].  Image f's parameters after the call are
+ * bit-identical to gi2d_fit_step's on slice f.  The reference fits the images of a dataset one
+ * after the other (/root/reference/train.py:366-372); one 768x512 fit leaves most of the chip
+ * idle, a batch fills it.  Whole frames only.  No counterpart in the reference. */
+int gi2d_fit_step_batch(gi2d_workspace *ws, int kind, int frames, float *xyz, float *cov_a,
+                        float *cov_b, float *features, const float *opacity,
+                        const float *background, const float *gt_chw, int N, int H, int W,
+                        const gi2d_conv *conv, float *xys, float *depths, int *radii,
+                        float *conics, int *num_tiles_hit, float *images, float *loss_partials,
+                        float *const *exp_avg, float *const *exp_avg_sq,
+                        float *const *exp_avg_diff, float *const *neg_pre_grad,
+                        const gi2d_adan_hyper *hyper, void *stream);
+
 /* gi2d_fit_step split where a tile-row sharded fit exchanges gradients (every rank holds all
  * parameters and the optimizer state, and rasterises its own band of tile rows, see
  * gi2d_workspace_set_rows):

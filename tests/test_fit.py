@@ -330,3 +330,49 @@ def test_sharded_fit_on_one_device_follows_the_unsharded_fit(kind, world):
         for f in ranks[1:]:
             assert torch.equal(f.params[k], ranks[0].params[k]), k
         assert _maxrel(ranks[0].params[k], ref.params[k]) <= 2e-5, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,F,N,H,W,K", [("cholesky", 3, 1500, 96, 128, 25),
+                                            ("rs", 2, 1200, 80, 112, 25),
+                                            ("cholesky", 5, 30000, 512, 768, 12)])
+def test_batch_fitter_gives_every_image_its_own_fit(kind, F, N, H, W, K):
+    """F images fitted in lockstep by one call of two launches: image f's parameters, optimizer
+    state and losses are, bit for bit, those of a FusedFitter that fits it alone -- also across
+    an outside edit of the parameters (the chained projection is dropped and redone)."""
+    from gaussianimage_amd.fit import BatchFitter, FusedFitter
+    per = []
+    for f in range(F):
+        if kind == "cholesky":
+            xyz, chol, feat = synth.cholesky_params(N, seed=40 + f)
+            per.append({"_xyz": xyz, "_cholesky": chol, "_features_dc": feat})
+        else:
+            xyz, sc, rot, feat = synth.rs_params(N, seed=40 + f)
+            per.append({"_xyz": xyz, "_scaling": sc, "_rotation": rot, "_features_dc": feat})
+    gts = torch.stack([synth.target_image(H, W, seed=f)[0] for f in range(F)]).to(DEV).contiguous()
+    singles = [FusedFitter(N, H, W, kind=kind, device=DEV, lr=5e-3, params=p, keep_image=False)
+               for p in per]
+    batch = BatchFitter(F, N, H, W, kind=kind, device=DEV, lr=5e-3,
+                        params={k: torch.stack([p[k] for p in per]) for k in per[0]})
+    for it in range(K):
+        if it == K // 2:
+            # an edit from outside between two iterations
+            for fit in singles:
+                fit.params["_features_dc"].mul_(0.9)
+            batch.params["_features_dc"].mul_(0.9)
+        for f, fit in enumerate(singles):
+            fit.step(gts[f:f + 1])
+        batch.step(gts)
+        if it % 6 == 5 or it == K - 1:
+            losses = batch.losses()
+            for f, fit in enumerate(singles):
+                # (the per-tile sums are the kernels'; their total is added up on the host)
+                assert torch.equal(batch.loss_partials[f], fit.loss_partials), (it, f)
+                assert abs(float(losses[f]) - fit.loss()) <= 1e-12
+    assert batch.overflowed_frames == 0
+    for f, fit in enumerate(singles):
+        for k in fit.params:
+            assert torch.equal(batch.params[k][f], fit.params[k]), (f, k)
+            for s in fit.state[k]:
+                assert torch.equal(batch.state[k][s][f], fit.state[k][s]), (f, k, s)
+    assert float(batch.losses()[0]) < 1.0

@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench  # noqa: E402
 from gaussianimage_amd import _lib  # noqa: E402
 from gaussianimage_amd.pipeline import FrameBatch  # noqa: E402

@@ -31,7 +31,7 @@ def avg(kernel_part, counter, skip_first=2):
 out = {"source": source}
 # (the batch launch's rasteriser: first pass, one colour set, records; any workgroup shape)
 for tag, part in (("raster_fwd", r"rasterize_sum_fwd_kernel<true, false, 1, \d, true>"),
-                  ("project", r"project_agg_fwd_kernel<false>"),
+                  ("project", r"project_agg_fwd_kernel<false, false>"),
                   ("project_direct", r"project_cholesky_fwd_kernel<false>")):
     f, w = avg(part, "FETCH_SIZE"), avg(part, "WRITE_SIZE")
     if f is not None and w is not None:
