@@ -583,6 +583,9 @@ def secondary(args, device, batch, run, batch_in, B, I_8d, I_held, raster_batch_
         gts = torch.stack([synth.target_image(H, W, seed=f)[0] for f in range(B)]).to(
             device).contiguous()
         bfit = BatchFitter(B, N, H, W, kind=kind, device=device)
+        if fp != 1.0 and kind == "cholesky":   # (the workload's footprint, as in make_fitter)
+            bound = torch.tensor([0.5, 0.0, 0.5], device=device)
+            bfit.params["_cholesky"].copy_((bfit.params["_cholesky"] + bound) * fp - bound)
         bms = bench_region(lambda: bfit.step(gts), max(20, k // 2), 10)
         out["train_step"]["fused_batch"] = {
             "images": B, "ms_per_step": bms, "ms_per_image_iteration": bms / B,
