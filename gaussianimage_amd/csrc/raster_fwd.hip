@@ -110,10 +110,12 @@ int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *conics,
         // times over, one wave per tile pays the per-tile work -- staging, the sort, the
         // barriers -- once instead of four times, whatever the tiles hold.  Measured at 768x512 /
         // 30 000 Gaussians, 1 / 2 / 4 pixels per lane: 8 frames 37 / 32 / 33 us, 24 frames
-        // 95 / 76 / 69 us; one frame 11 / 13 / 16 us)
+        // 95 / 76 / 69 us; one frame 11 / 13 / 16 us.  Long lists -- fitted Gaussians, three times
+        // the footprint, up to 300 per tile -- keep two waves: 24 frames 237 / 227 / 250 us)
         if (ppl == 0) {
             const long long launch_tiles = (long long)T * frames;
             ppl = launch_tiles >= GI2D_PPL4_MIN_TILES ? 4 : (launch_tiles >= GI2D_PPL2_MIN_TILES ? 2 : 1);
+            if (ppl == 4 && frames > 1 && ws->h_status[0] > 128) ppl = 2;
         }
     }
     const dim3 grid(T, frames);
