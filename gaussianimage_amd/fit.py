@@ -204,7 +204,8 @@ class FusedFitter:
 
 class BatchFitter:
     """``frames`` images of one size fitted in lockstep by ``gi2d_fit_step_batch``: the fused
-    iteration of ``FusedFitter`` over all of them in the same two launches.  Parameters, optimizer
+    iteration of ``FusedFitter`` over all of them in one call (three launches from four images
+    on).  Parameters, optimizer
     state and outputs are ``[frames, N, ...]`` tensors (``params["_xyz"][f]`` is image f's
     ``_xyz``); targets are one contiguous ``[frames, 3, H, W]`` tensor.  Image f follows, bit for
     bit, the trajectory ``FusedFitter`` gives it alone.  For the reference's loop over the images

@@ -355,7 +355,9 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
                   const gi2d_adan_hyper *hyper, void *stream);
 
 /* gi2d_fit_step for `frames` images of one size fitted in lockstep -- the same iteration number,
- * learning rate and N Gaussians each -- in the same TWO launches: every parameter, optimizer-state
+ * learning rate and N Gaussians each -- in one call (two launches for fewer than four images;
+ * three from four on, where the next lists are filled by the batch projection instead of the
+ * tail's lanes): every parameter, optimizer-state
  * and per-Gaussian tensor is [frames][N][...] (the four state arrays hold one pointer per
  * parameter tensor, as in gi2d_fit_step), gt_chw is [frames][3][H][W], images (optional)
  * [frames][H][W][3], loss_partials [frames][tiles].  Image f's parameters after the call are
