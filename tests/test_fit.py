@@ -376,3 +376,49 @@ def test_batch_fitter_gives_every_image_its_own_fit(kind, F, N, H, W, K):
             for s in fit.state[k]:
                 assert torch.equal(batch.state[k][s][f], fit.state[k][s]), (f, k, s)
     assert float(batch.losses()[0]) < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [2, 5])
+def test_growing_gaussians_do_not_stop_a_batch_fit(F):
+    """The batch fit under the same stress as the single fit: footprints that outgrow the lists'
+    capacity cost the overflowed tiles one step's gradient, the workspace grows, nothing becomes
+    NaN -- with the chained tail (fewer than four images) and with the separate batch projection."""
+    from gaussianimage_amd.fit import BatchFitter
+    H, W, N = 64, 80, 3000
+    torch.manual_seed(2)
+    fit = BatchFitter(F, N, H, W, kind="cholesky", device=DEV)
+    gts = torch.stack([synth.target_image(H, W, seed=f)[0] for f in range(F)]).to(DEV).contiguous()
+    for _ in range(5):
+        fit.step(gts)
+    cap0 = fit.ws.info()["capacity"]
+    fit.params["_cholesky"].mul_(5.0).add_(2.0)
+    for _ in range(6):
+        fit.step(gts)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        fit.step(gts)
+    torch.cuda.synchronize()
+    assert fit.overflowed_frames >= 1
+    assert fit.ws.info()["capacity"] > cap0
+    for p in fit.params.values():
+        assert torch.isfinite(p).all()
+    for _ in range(3):
+        fit.step(gts)
+    assert torch.isfinite(fit.losses()).all()
+
+
+@pytest.mark.gpu
+def test_batch_fitter_rejects_what_it_cannot_fit():
+    from gaussianimage_amd.fit import BatchFitter
+    with pytest.raises(ValueError):
+        BatchFitter(0, 10, 32, 32, device=DEV)
+    with pytest.raises(ValueError):
+        BatchFitter(2, 10, 32, 32, device=DEV, params={"_xyz": torch.zeros(10, 2),
+                                                        "_cholesky": torch.zeros(10, 3),
+                                                        "_features_dc": torch.zeros(10, 3)})
+    fit = BatchFitter(2, 10, 32, 32, device=DEV)
+    with pytest.raises(ValueError):
+        fit.step(torch.zeros(1, 3, 32, 32, device=DEV))
+    fit.step(torch.zeros(2, 3, 32, 32, device=DEV))   # (and an empty-ish problem just runs)
+    assert torch.isfinite(fit.losses()).all()
