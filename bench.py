@@ -670,6 +670,8 @@ def main():
                          "a second workload blur a profiler's per-kernel averages)")
     ap.add_argument("--raster-ppl", type=int, default=0, choices=[0, 1, 2, 4],
                     help="pixels per lane of the forward rasteriser (0 = the library's choice)")
+    ap.add_argument("--no-records", action="store_true",
+                    help="the rasteriser gathers the operator tensors instead of per-Gaussian records")
     ap.add_argument("--project-form", type=int, default=0,
                     help="how the projection fills the lists (GI2D_OPT_PROJECT_AGG; 0 = the "
                          "library's choice)")
@@ -719,6 +721,8 @@ def main():
     batch = FrameBatch(B, N, H, W, kind=kind, device=device)
     if args.raster_ppl:
         batch.ws.set_raster_ppl(args.raster_ppl)
+    if args.no_records:
+        batch.ws.set_records(False)
     if args.project_form:
         from gaussianimage_amd import _lib
         _lib.check(_lib.lib.gi2d_workspace_set_option(batch.ws.handle, _lib.OPT_PROJECT_AGG,
