@@ -128,6 +128,29 @@ def build_torch_ops(force=False, verbose=False):
     return TORCH_OPS_LIB
 
 
+C_HOST_SRC = os.path.join(os.path.dirname(_HERE), "examples", "c_host", "render_batch.c")
+C_HOST_BIN = os.path.join(os.path.dirname(_HERE), "examples", "c_host", "render_batch")
+
+
+def build_examples(force=False, verbose=False):
+    """The C host of examples/c_host (plain C99 through gcc: the C ABI needs no C++ and no HIP
+    compiler on the caller's side), linked to libgi2d.so and the HIP runtime."""
+    deps = [C_HOST_SRC, os.path.join(os.path.dirname(_HERE), "include", "gi2d.h"), LIB]
+    if not force and os.path.exists(C_HOST_BIN) and \
+            all(os.path.getmtime(d) <= os.path.getmtime(C_HOST_BIN) for d in deps):
+        return C_HOST_BIN
+    cmd = [shutil.which("gcc") or "gcc", "-O2", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__",
+           "-I", "/opt/rocm/include", "-I", os.path.join(os.path.dirname(_HERE), "include"),
+           C_HOST_SRC, "-o", C_HOST_BIN, "-L", CSRC, "-lgi2d", "-L", "/opt/rocm/lib",
+           "-lamdhip64", "-Wl,-rpath,$ORIGIN/../../gaussianimage_amd/csrc",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return C_HOST_BIN
+
+
 if __name__ == "__main__":
     print(build_native(force=True, verbose=True))
     print(build_torch_ops(force=True, verbose=True))
+    print(build_examples(force=True, verbose=True))
