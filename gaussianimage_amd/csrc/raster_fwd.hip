@@ -113,8 +113,10 @@ int raster_fwd_impl(gi2d_workspace *ws, const float *xys, const float *conics,
         // 95 / 76 / 69 us; one frame 11 / 13 / 16 us.  Long lists -- fitted Gaussians, three times
         // the footprint, up to 300 per tile -- keep two waves: 24 frames 237 / 227 / 250 us)
         if (ppl == 0) {
+            // (small batches: two frames of 1536 tiles 84 / 89 / 80 k frames/s, four 106 / 110 / 108)
             const long long launch_tiles = (long long)T * frames;
-            ppl = launch_tiles >= GI2D_PPL4_MIN_TILES ? 4 : (launch_tiles >= GI2D_PPL2_MIN_TILES ? 2 : 1);
+            const long long two_from = frames > 1 ? 3072 : GI2D_PPL2_MIN_TILES;
+            ppl = launch_tiles >= GI2D_PPL4_MIN_TILES ? 4 : (launch_tiles >= two_from ? 2 : 1);
             if (ppl == 4 && frames > 1 && ws->h_status[0] > 128) ppl = 2;
         }
     }
