@@ -422,3 +422,24 @@ def test_batch_fitter_rejects_what_it_cannot_fit():
         fit.step(torch.zeros(1, 3, 32, 32, device=DEV))
     fit.step(torch.zeros(2, 3, 32, 32, device=DEV))   # (and an empty-ish problem just runs)
     assert torch.isfinite(fit.losses()).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,N,H,W", [(2, 0, 40, 56), (5, 1, 16, 16), (3, 5, 1, 1), (4, 300, 33, 17)])
+def test_batch_fitter_on_degenerate_sizes(F, N, H, W):
+    """The same degenerate problems in a batch: every image follows its single fit."""
+    from gaussianimage_amd.fit import BatchFitter, FusedFitter
+    gts = torch.stack([synth.target_image(H, W, seed=f)[0] for f in range(F)]).to(DEV).contiguous()
+    torch.manual_seed(9)
+    batch = BatchFitter(F, N, H, W, device=DEV)
+    singles = [FusedFitter(N, H, W, device=DEV,
+                           params={k: v[f] for k, v in batch.params.items()}) for f in range(F)]
+    for _ in range(4):
+        batch.step(gts)
+        for f, fit in enumerate(singles):
+            fit.step(gts[f:f + 1])
+    for f, fit in enumerate(singles):
+        assert torch.equal(batch.loss_partials[f], fit.loss_partials), f
+        for k in fit.params:
+            assert torch.equal(batch.params[k][f], fit.params[k]), (f, k)
+            assert torch.isfinite(batch.params[k]).all()
