@@ -151,8 +151,15 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
 //   1. projects them, counting their tiles in a histogram in LDS (LDS atomics cost next to
 //      nothing);
 //   2. reserves, with ONE returning atomic per tile it touched, that many places in the tile's
-//      segment, and leaves the first place in the histogram word;
-//   3. walks its Gaussians' boxes again: a returning LDS atomic hands out the places.
+//      segment;
+//   3. while those atomics are in flight, walks its Gaussians' boxes again and gathers the
+//      pairs per tile in an LDS stage (a prefix sum of the histogram gives each tile's run, a
+//      returning LDS atomic the place inside it);
+//   4. copies the stage out, consecutive lanes to consecutive places of a tile's run (runs of
+//      ~8 ids instead of 64 scattered 4-byte stores per wave).
+// (Measured as a launch of its own at 24 x 30 000 Gaussians, steps 2-4 done one after the other
+// with scattered stores took 21.7 us: 4.5 us loads and histogram, 6.8 us reservations, 4 us
+// placement, 6.5 us stores.)
 // A frame of N Gaussians costs (workgroups per frame) x (tiles touched) counter atomics instead
 // of one per pair: 8 workgroups per 30 000-Gaussian frame -> 12 000 instead of 57 000.  Lists are
 // the same sets as the direct kernels' (the order inside a list is restored by the sort that
@@ -161,6 +168,10 @@ __global__ __launch_bounds__(256) void project_rs_fwd_kernel(
 #define AGG_THREADS 1024
 #define AGG_ROUNDS 8
 #define AGG_MAX_TILES 4096
+#define AGG_STAGE 16384  // (tile, Gaussian) pairs a workgroup can gather in LDS
+static_assert(AGG_MAX_TILES == 4 * AGG_THREADS && AGG_MAX_TILES <= (1 << 12) &&
+                  AGG_ROUNDS * AGG_THREADS <= (1 << 13),
+              "the stage words and the four tiles per lane assume these sizes");
 
 // RAW: the model's raw parameters, activated here (as in project_*_fwd_kernel<RAW>).
 template <bool RS, bool RAW>
@@ -168,15 +179,16 @@ __global__ __launch_bounds__(AGG_THREADS) void project_agg_fwd_kernel(
     const float *__restrict__ means, const float *__restrict__ cov_a,
     const float *__restrict__ cov_b, ProjArgs a, int chunk)
 {
-    __shared__ int hist[AGG_MAX_TILES];
+    __shared__ __attribute__((aligned(16))) int hist[AGG_MAX_TILES];
+    __shared__ int stage[AGG_STAGE];
+    __shared__ int wave_sum[AGG_THREADS / 64];
     const int tid = threadIdx.x, f = blockIdx.y;
-    const int T = a.tiles_per_frame;
     if (tid == 0 && blockIdx.x == 0 && f == 0) publish_status(a.status, a.h_status, a.generation);
     to_frame(a, f);
     means += (size_t)f * 2 * a.N;
     cov_a += (size_t)f * (RS ? 2 : 3) * a.N;
     if (RS) cov_b += (size_t)f * a.N;
-    for (int t = tid; t < T; t += AGG_THREADS) hist[t] = 0;
+    *reinterpret_cast<int4 *>(hist + (AGG_MAX_TILES / AGG_THREADS) * tid) = make_int4(0, 0, 0, 0);
     __syncthreads();
     const int g0 = blockIdx.x * chunk, g1 = min(a.N, g0 + chunk);
     int boxes[AGG_ROUNDS];  // x0 | x1 << 8 | y0 << 16 | y1 << 24 of each of my Gaussians
@@ -234,30 +246,85 @@ __global__ __launch_bounds__(AGG_THREADS) void project_agg_fwd_kernel(
         }
     }
     __syncthreads();
+    // Each lane looks after PER_LANE consecutive tiles.  The reservations are put in flight
+    // first and used last: a returning atomic's round trip is the longest wait of this kernel
+    // (and every workgroup of the launch reaches this point at about the same time), so the
+    // ids are meanwhile gathered per tile in LDS, where only the order inside the workgroup's
+    // own run of each tile has to be settled.
+    constexpr int PER_LANE = AGG_MAX_TILES / AGG_THREADS;
+    const int t4 = PER_LANE * tid;
+    int cnt[PER_LANE], base[PER_LANE], off[PER_LANE];
     {
-        // (all of a lane's counter atomics are put in flight before the first result is used: a
-        // returning atomic's round trip is the longest wait of this kernel)
-        constexpr int PER_LANE = AGG_MAX_TILES / AGG_THREADS;
-        int cnt[PER_LANE], base[PER_LANE];
-#pragma unroll
-        for (int k = 0; k < PER_LANE; ++k) {
-            const int t = tid + k * AGG_THREADS;
-            cnt[k] = t < T ? hist[t] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < PER_LANE; ++k) {
-            const int t = tid + k * AGG_THREADS;
-            base[k] = 0;
-            // (a tile this workgroup never touched keeps a zero nobody reads)
-            if (cnt[k] > 0)
-                base[k] = atomicAdd(&a.lists.tile_count[(size_t)t * CNT_STRIDE], cnt[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < PER_LANE; ++k)
-            if (cnt[k] > 0) hist[tid + k * AGG_THREADS] = base[k];
+        const int4 c = *reinterpret_cast<const int4 *>(hist + t4);
+        cnt[0] = c.x;
+        cnt[1] = c.y;
+        cnt[2] = c.z;
+        cnt[3] = c.w;
     }
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER_LANE; ++k) {
+        base[k] = 0;
+        // (a tile this workgroup never touched keeps a zero nobody reads)
+        if (cnt[k] > 0)
+            base[k] = atomicAdd(&a.lists.tile_count[(size_t)(t4 + k) * CNT_STRIDE], cnt[k]);
+    }
+    // exclusive prefix of the counts over the tiles: where each tile's run starts in the stage
+    const int lane = tid & 63, wave = tid >> 6;
+    const int mine = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();  // (also: every lane has taken its counts out of the histogram)
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < AGG_THREADS / 64; ++w) {
+        const int v = wave_sum[w];
+        before += w < wave ? v : 0;
+        total += v;
+    }
+    off[0] = before + incl - mine;
+#pragma unroll
+    for (int k = 1; k < PER_LANE; ++k) off[k] = off[k - 1] + cnt[k - 1];
     const int C = a.lists.C;
+    if (total <= AGG_STAGE) {
+        // the histogram words become the tiles' cursors into the stage
+        *reinterpret_cast<int4 *>(hist + t4) = make_int4(off[0], off[1], off[2], off[3]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < AGG_ROUNDS; ++r) {
+            const int b = boxes[r];
+            if (b == 0) continue;
+            const int x0 = b & 255, x1 = (b >> 8) & 255, y0 = (b >> 16) & 255, y1 = (b >> 24) & 255;
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) {
+                    const int t = ty * a.tiles_x + tx;
+                    // tile (12 bits) and the Gaussian's place in this workgroup's run (13 bits)
+                    stage[atomicAdd(&hist[t], 1)] = (t << 13) | (r * AGG_THREADS + tid);
+                }
+        }
+        __syncthreads();
+        // stage index -> place in the tile's segment: + (first reserved place - run start)
+        *reinterpret_cast<int4 *>(hist + t4) =
+            make_int4(base[0] - off[0], base[1] - off[1], base[2] - off[2], base[3] - off[3]);
+        __syncthreads();
+        // consecutive lanes write consecutive places of a tile's run
+        for (int i = tid; i < total; i += AGG_THREADS) {
+            const int w = stage[i];
+            const int t = w >> 13;
+            const int pos = hist[t] + i;
+            // (ids beyond a segment's capacity are dropped; the counter has counted them)
+            if (pos < C) a.lists.seg[(size_t)t * C + pos] = g0 + (w & 8191);
+        }
+        return;
+    }
+    // more pairs than the stage holds (large footprints): every pair's place comes from a
+    // returning LDS atomic on its tile's first reserved place, and the ids go out scattered
+    *reinterpret_cast<int4 *>(hist + t4) = make_int4(base[0], base[1], base[2], base[3]);
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < AGG_ROUNDS; ++r) {
         const int b = boxes[r];
@@ -268,7 +335,6 @@ __global__ __launch_bounds__(AGG_THREADS) void project_agg_fwd_kernel(
             for (int tx = x0; tx < x1; ++tx) {
                 const int t = ty * a.tiles_x + tx;
                 const int pos = atomicAdd(&hist[t], 1);
-                // (ids beyond a segment's capacity are dropped; the counter has counted them)
                 if (pos < C) a.lists.seg[(size_t)t * C + pos] = g;
             }
     }

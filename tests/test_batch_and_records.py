@@ -153,14 +153,18 @@ def test_records_change_no_bit_of_a_fit_or_a_decode(kind):
                                              ("cholesky", 6, 1500, 33, 17, 1.0),
                                              ("cholesky", 1, 70000, 512, 768, 1.0),
                                              ("rs", 5, 30000, 512, 768, 1.0),
-                                             ("cholesky", 3, 4000, 700, 40, 3.0)])
+                                             ("cholesky", 3, 4000, 700, 40, 3.0),
+                                             ("cholesky", 1, 8192, 512, 512, 20.0),
+                                             ("rs", 2, 3000, 256, 256, 6.0)])
 def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
     """The projection that counts its tiles in LDS (one counter atomic per tile a workgroup
     touches) and the one that fills the lists by bands of tile rows (no counter atomics) against
     the one-atomic-per-pair form: same outputs, same lists, same images -- forced on for single
     frames, for runs of several Gaussians per lane (70 000 Gaussians: the workgroups-per-frame
     floor of the first, beyond the limit of the second), for a frame smaller than one workgroup
-    and for a tall frame whose bands hold several tile rows."""
+    for a tall frame whose bands hold several tile rows, and for footprints so large that a
+    workgroup's (tile, Gaussian) pairs exceed what it can gather in LDS (8192 Gaussians, ~20
+    tiles each) or nearly do."""
     from gaussianimage_amd import _lib
     from gaussianimage_amd.pipeline import FrameBatch
     per = [_inputs(kind, N, 30 + f, fp) for f in range(F)]
@@ -180,6 +184,8 @@ def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
     for other in got[1:]:
         for x, y in zip(got[0], other):
             assert torch.equal(x, y)
+    if fp == 20.0:   # (8 workgroups of 1024 Gaussians, 16384 pairs gathered at most)
+        assert int(got[0][1][-1]) > 8 * 16384
 
 
 @pytest.mark.parametrize("depth", [1, 2, 3])
