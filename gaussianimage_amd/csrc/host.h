@@ -47,6 +47,11 @@ struct gi2d_workspace {
     int project_agg = 0;
     int *d_box = nullptr;            // packed tile boxes of the band-wise list filling
     int64_t box_cap = 0;
+    // list filling through cells (large frames): per-cell counters and buckets
+    int *d_cell_count = nullptr;     // [GI2D_CELLS_MAX][CNT_STRIDE], zero between frames
+    void *d_cell_bucket = nullptr;   // [cells][N] (id, packed box)
+    int64_t cell_bucket_cap = 0;     // entries the buckets hold in all
+    bool fixed_memory = false;       // the workspace lives in memory that cannot grow
     int no_records = 0;  // 1: projections never write the rasteriser's records (no-alloc path)
     // Second list set (same tiles_cap x seg_cap): the fitting tail fills it with the NEXT
     // iteration's lists while it still reads the current ones; the sets then swap roles.
@@ -123,6 +128,12 @@ struct ExtraSets {
 // 59 / 44 / 38 us with 1 / 2 / 4; ~1020x768 / 50k (10 752 tiles) 14.6 / 14.6 / 20.3 us;
 // 768x512 / 30k (1536 tiles, ~48 per tile) 10 / 11.5 / 18 us.
 #define GI2D_PPL2_MIN_TILES 12288
+// List filling through cells of tiles (project.hip): frames from this size on take it by
+// themselves; the buckets (cells x N entries of 8 bytes) may take this much memory.
+#define GI2D_CELLS_MAX 1024
+#define GI2D_CELLS_MIN_TILES 8192
+#define GI2D_CELLS_MIN_GAUSSIANS 32768
+#define GI2D_CELLS_MAX_BYTES ((int64_t)1 << 30)
 #define GI2D_PPL4_MIN_TILES 20480
 
 // A sparse frame -- many tiles, none of whose lists has ever held more than a wave's worth of
@@ -146,6 +157,7 @@ static inline int ws_tiles(const gi2d_workspace *ws) { return ws->frames * ws_ti
 int ensure_lists(gi2d_workspace *ws, int T, int C);
 int ensure_records(gi2d_workspace *ws, int64_t count);
 int ensure_boxes(gi2d_workspace *ws, int64_t count);
+int ensure_cells(gi2d_workspace *ws, int cells, int N);
 int bin_tiles_impl(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
                    int tiles_y, int flags, void *stream, int frames);
 int wanted_cap(const gi2d_workspace *ws, long long seen);

@@ -184,6 +184,26 @@ int ensure_records(gi2d_workspace *ws, int64_t count)
     return GI2D_OK;
 }
 
+// Counters and buckets of `cells` cells of N entries each; the device is current.
+int ensure_cells(gi2d_workspace *ws, int cells, int N)
+{
+    if (cells < 1 || cells > GI2D_CELLS_MAX) return GI2D_E_INVALID;
+    if (!ws->d_cell_count) {
+        const size_t bytes = sizeof(int) * (size_t)GI2D_CELLS_MAX * CNT_STRIDE;
+        HIP_TRY(hipMalloc(&ws->d_cell_count, bytes));
+        HIP_TRY(hipMemset(ws->d_cell_count, 0, bytes));
+    }
+    const int64_t want = (int64_t)cells * N;
+    if (ws->cell_bucket_cap >= want) return GI2D_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (ws->d_cell_bucket) (void)hipFree(ws->d_cell_bucket);
+    ws->d_cell_bucket = nullptr;
+    ws->cell_bucket_cap = 0;
+    HIP_TRY(hipMalloc(&ws->d_cell_bucket, 2 * sizeof(int) * (size_t)want));
+    ws->cell_bucket_cap = want;
+    return GI2D_OK;
+}
+
 // One packed tile box per Gaussian for `count` Gaussians; the device is current.
 int ensure_boxes(gi2d_workspace *ws, int64_t count)
 {
@@ -352,6 +372,8 @@ int gi2d_workspace_destroy(gi2d_workspace *ws)
     if (ws->d_gslots) (void)hipFree(ws->d_gslots);
     if (ws->d_rec) (void)hipFree(ws->d_rec);
     if (ws->d_box) (void)hipFree(ws->d_box);
+    if (ws->d_cell_count) (void)hipFree(ws->d_cell_count);
+    if (ws->d_cell_bucket) (void)hipFree(ws->d_cell_bucket);
     if (ws->d_status) (void)hipFree(ws->d_status);
     if (ws->h_status) (void)hipHostFree(ws->h_status);
     delete ws;
@@ -381,7 +403,7 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
             ws->chain_pending = false;
             return GI2D_OK;
         case GI2D_OPT_PROJECT_AGG:
-            if (value < 0 || value > 3) return GI2D_E_INVALID;
+            if (value < 0 || value > 4) return GI2D_E_INVALID;
             ws->project_agg = value;
             return GI2D_OK;
         case GI2D_OPT_RECORDS:

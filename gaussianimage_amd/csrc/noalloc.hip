@@ -89,6 +89,7 @@ int gi2d_render_frame_noalloc(const gi2d_frame_args *a, int per_tile_capacity)
     w.seg_cap = (int)C;
     w.min_seg_cap = WAVE;
     w.no_records = 1;  // (per-Gaussian records would need a buffer that grows with N)
+    w.fixed_memory = true;
     if (w.generation == 0) w.generation = 1;
     w.n_binned = a->N;
     w.tiles_x = tiles_x;

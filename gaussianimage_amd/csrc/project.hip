@@ -444,6 +444,251 @@ __global__ __launch_bounds__(AGG_THREADS) void fill_bands_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Large frames: list filling through CELLS of 2^k x 2^k tiles, two launches, no atomic on any
+// tile counter.  A frame of tens of thousands of tiles and Gaussians in no spatial order defeats
+// the aggregation above (a workgroup's Gaussians touch almost as many tiles as they have pairs),
+// and one returning atomic per pair is what the part sustains only 2e10 of per second (25 us
+// for the 497 000 pairs of a 3840x2160 frame of 200 000 Gaussians).
+//   1. project_cells_fwd_kernel -- one lane per Gaussian, workgroups of 1024: outputs, record,
+//      culled tile box; a histogram of the CELLS the boxes touch in LDS, one returning atomic per
+//      (workgroup, cell) on the cell's counter, and -- gathered per cell in LDS while those are
+//      in flight -- (id, packed box) into the cell's bucket in runs.  A bucket holds N entries:
+//      a Gaussian enters a cell once, so no bucket can overflow.
+//   2. fill_cells_kernel -- one workgroup per cell OWNS the cell's tiles: it reads its bucket
+//      once (a few entries per lane, kept in registers), counts the tiles of the boxes (clipped
+//      to the cell) in LDS, stores the counters plainly, gathers the ids per tile in LDS and
+//      copies them out in runs.
+// Both passes are chains of a few dependent phases, so small cells (8 x 8 tiles: a bucket is
+// about one entry per lane) serve pass 2 best; pass 1 is not bound by its reservations
+// (measured at 3840x2160 / 200 000 Gaussians: 13.6 us with 510 cells, 12.7 us with 135, while
+// pass 2 took 6.3 us against 10.7 us with four workgroups per 16 x 16 cell; 27.6 us for the
+// one-atomic-per-pair projection).
+// Lists are the same sets as the other forms' (the rasteriser's sort restores the order).  Each
+// side < 256 tiles.
+// ------------------------------------------------------------------------------------------
+#define CELL_THREADS 1024
+#define CELL_MAX GI2D_CELLS_MAX  // cells of a frame, at most (one lane, one histogram word each)
+static_assert(CELL_MAX == CELL_THREADS, "one lane per cell");
+#define CELL_MAX_LOG2 5      // tiles per cell side, at most 32 (a cell's tiles: one lane each)
+#define CELL_STAGE1 4096     // (cell, Gaussian) pairs a workgroup of pass 1 gathers in LDS
+#define CELL_STAGE2 8192     // (tile, Gaussian) pairs a workgroup of pass 2 gathers in LDS
+#define CELL_KEEP 2          // bucket entries per lane that pass 2 keeps in registers
+
+struct CellGrid {
+    int log2_side;      // a cell is 2^log2_side tiles wide and high
+    int cells_x, cells;
+    int row0, row1;     // the tile rows the lists cover
+    int *count;         // [cells][CNT_STRIDE], zero between frames
+    int2 *bucket;       // [cells][cap]: (Gaussian id, x0 | x1 << 8 | y0 << 16 | y1 << 24)
+    int cap;
+};
+
+// exclusive prefix of v over the 1024 lanes of the workgroup; the sum of all in `total`
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wave_sum, int &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int o = wave_sum[w];
+        before += w < wave ? o : 0;
+        total += o;
+    }
+    return before + incl - v;
+}
+
+template <bool RS, bool RAW>
+__global__ __launch_bounds__(CELL_THREADS) void project_cells_fwd_kernel(
+    const float *__restrict__ means, const float *__restrict__ cov_a,
+    const float *__restrict__ cov_b, ProjArgs a, CellGrid cg)
+{
+    __shared__ int chist[CELL_MAX];
+    __shared__ int2 stage[CELL_STAGE1];
+    __shared__ int wave_sum[CELL_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x * CELL_THREADS + tid;
+    if (g == 0) publish_status(a.status, a.h_status, a.generation);
+    chist[tid] = 0;
+    __syncthreads();
+    int packed = 0, cx0 = 0, cx1 = 0, cy0 = 0, cy1 = 0;  // the box, and the cells it touches
+    if (g < a.N) {
+        float mx = means[2 * g], my = means[2 * g + 1];
+        if (RAW) {
+            mx = tanhf(mx);
+            my = tanhf(my);
+        }
+        float sxx, sxy, syy;
+        if (RS) {
+            float theta = cov_b[g];
+            float s1 = cov_a[2 * g], s2 = cov_a[2 * g + 1];
+            if (RAW) {
+                s1 = fabsf(s1 + 0.5f);
+                s2 = fabsf(s2 + 0.5f);
+                theta = (1.0f / (1.0f + expf(-theta))) * 2.0f * 3.14159274f;
+            }
+            float sn, cs;
+            gi2d_sincos_f32(theta, &sn, &cs);
+            const float q1 = s1 * s1, q2 = s2 * s2;
+            sxx = cs * cs * q1 + sn * sn * q2;
+            sxy = cs * sn * (q1 - q2);
+            syy = sn * sn * q1 + cs * cs * q2;
+        } else {
+            float l11 = cov_a[3 * g], l21 = cov_a[3 * g + 1], l22 = cov_a[3 * g + 2];
+            if (RAW) {
+                l11 = l11 + 0.5f;
+                l22 = l22 + 0.5f;
+            }
+            sxx = l11 * l11;
+            sxy = l11 * l21;
+            syy = l21 * l21 + l22 * l22;
+        }
+        float cr = 0.f, cgr = 0.f, cb = 0.f;
+        if (a.rec.rec != nullptr) {
+            cr = a.rec_colors[3 * g];
+            cgr = a.rec_colors[3 * g + 1];
+            cb = a.rec_colors[3 * g + 2];
+        }
+        TileBox box;
+        const bool listed = project_body(g, mx, my, sxx, sxy, syy, a.H, a.W, a.tiles_x, a.tiles_y,
+                                         a.center_bias, a.out, true, a.cull, a.rec, cr, cgr, cb,
+                                         box);
+        const int y0 = max(box.y0, cg.row0), y1 = min(box.y1, cg.row1);
+        if (listed && box.x1 > box.x0 && y1 > y0) {
+            packed = box.x0 | (box.x1 << 8) | (y0 << 16) | (y1 << 24);
+            cx0 = box.x0 >> cg.log2_side;
+            cx1 = ((box.x1 - 1) >> cg.log2_side) + 1;
+            cy0 = (y0 - cg.row0) >> cg.log2_side;
+            cy1 = ((y1 - 1 - cg.row0) >> cg.log2_side) + 1;
+            for (int cy = cy0; cy < cy1; ++cy)
+                for (int cx = cx0; cx < cx1; ++cx) atomicAdd(&chist[cy * cg.cells_x + cx], 1);
+        }
+    }
+    __syncthreads();
+    // lane = cell: reserve (in flight until the copy-out), and find each cell's run in the stage
+    const int cnt = chist[tid];  // (zero past the frame's cells)
+    int base = 0;
+    if (cnt > 0) base = atomicAdd(&cg.count[(size_t)tid * CNT_STRIDE], cnt);
+    int total;
+    const int off = block_exclusive_scan_1024(cnt, wave_sum, total);
+    if (total <= CELL_STAGE1) {
+        chist[tid] = off;  // the cell's cursor into the stage
+        __syncthreads();
+        for (int cy = cy0; cy < cy1; ++cy)
+            for (int cx = cx0; cx < cx1; ++cx) {
+                const int c = cy * cg.cells_x + cx;
+                stage[atomicAdd(&chist[c], 1)] = make_int2((c << 10) | tid, packed);
+            }
+        __syncthreads();
+        chist[tid] = base - off;  // stage index -> place in the cell's bucket
+        __syncthreads();
+        for (int i = tid; i < total; i += CELL_THREADS) {
+            const int2 e = stage[i];
+            const int c = e.x >> 10;
+            const int pos = chist[c] + i;
+            if (pos < cg.cap)
+                cg.bucket[(size_t)c * cg.cap + pos] =
+                    make_int2(blockIdx.x * CELL_THREADS + (e.x & 1023), e.y);
+        }
+        return;
+    }
+    // boxes over many cells (very large footprints): places from returning LDS atomics on the
+    // first reserved place, entries stored one by one
+    chist[tid] = base;
+    __syncthreads();
+    for (int cy = cy0; cy < cy1; ++cy)
+        for (int cx = cx0; cx < cx1; ++cx) {
+            const int c = cy * cg.cells_x + cx;
+            const int pos = atomicAdd(&chist[c], 1);
+            if (pos < cg.cap) cg.bucket[(size_t)c * cg.cap + pos] = make_int2(g, packed);
+        }
+}
+
+__global__ __launch_bounds__(CELL_THREADS) void fill_cells_kernel(
+    CellGrid cg, int tiles_x, int *__restrict__ tile_count, int *__restrict__ seg, int C)
+{
+    __shared__ int hist[CELL_THREADS];     // per tile of the cell: count, then cursor
+    __shared__ int start[CELL_THREADS];    // where the tile's run starts in the stage
+    __shared__ int tile_of[CELL_THREADS];  // the tile's index in the lists
+    __shared__ int stage[CELL_STAGE2];
+    __shared__ unsigned short owner[CELL_STAGE2];
+    __shared__ int wave_sum[CELL_THREADS / 64];
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const int n = min(cg.count[(size_t)c * CNT_STRIDE], cg.cap);
+    hist[tid] = 0;
+    __syncthreads();  // (every lane has read the counter)
+    if (tid == 0) cg.count[(size_t)c * CNT_STRIDE] = 0;  // for the next frame
+    const int side = 1 << cg.log2_side;
+    const int tx0 = (c % cg.cells_x) << cg.log2_side, tx1 = min(tiles_x, tx0 + side);
+    const int ty0 = cg.row0 + ((c / cg.cells_x) << cg.log2_side), ty1 = min(cg.row1, ty0 + side);
+    const int w = tx1 - tx0, nt = w * (ty1 - ty0);
+    const int2 *__restrict__ src = cg.bucket + (size_t)c * cg.cap;
+    // the first CELL_KEEP x 1024 entries stay in registers for the second walk; a longer
+    // bucket (Gaussians crowded into one cell) is read again
+    int2 kept[CELL_KEEP];
+#pragma unroll
+    for (int r = 0; r < CELL_KEEP; ++r) {
+        const int i = r * CELL_THREADS + tid;
+        kept[r] = i < n ? src[i] : make_int2(0, 0);  // (an empty box: x0 = x1)
+    }
+    auto walk = [&](auto &&visit) {
+        auto entry = [&](const int2 e) {
+            const int b = e.y;
+            const int x0 = max(b & 255, tx0), x1 = min((b >> 8) & 255, tx1);
+            const int y0 = max((b >> 16) & 255, ty0), y1 = min((b >> 24) & 255, ty1);
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) visit((ty - ty0) * w + tx - tx0, e.x);
+        };
+#pragma unroll
+        for (int r = 0; r < CELL_KEEP; ++r) entry(kept[r]);
+        for (int i = CELL_KEEP * CELL_THREADS + tid; i < n; i += CELL_THREADS) entry(src[i]);
+    };
+    walk([&](int lt, int) { atomicAdd(&hist[lt], 1); });
+    __syncthreads();
+    const int cnt = hist[tid];  // (zero past the cell's tiles)
+    int t = 0;
+    if (tid < nt) {
+        const int ly = tid / w;
+        t = (ty0 - cg.row0 + ly) * tiles_x + tx0 + (tid - ly * w);
+        // (the counters were zero: the rasteriser returns them to zero after reading them)
+        if (cnt > 0) tile_count[(size_t)t * CNT_STRIDE] = cnt;
+    }
+    tile_of[tid] = t;
+    int total;
+    const int off = block_exclusive_scan_1024(cnt, wave_sum, total);
+    start[tid] = off;
+    const bool staged = total <= CELL_STAGE2;
+    hist[tid] = staged ? off : 0;
+    __syncthreads();
+    walk([&](int lt, int id) {
+        const int p = atomicAdd(&hist[lt], 1);
+        if (staged) {
+            stage[p] = id;
+            owner[p] = (unsigned short)lt;
+        } else if (p < C) {
+            // (ids beyond a segment's capacity are dropped; the counter has counted them)
+            seg[(size_t)tile_of[lt] * C + p] = id;
+        }
+    });
+    if (!staged) return;
+    __syncthreads();
+    // consecutive lanes write consecutive places of a tile's run
+    for (int i = tid; i < total; i += CELL_THREADS) {
+        const int lt = owner[i];
+        const int pos = i - start[lt];
+        if (pos < C) seg[(size_t)tile_of[lt] * C + pos] = stage[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Codec decode (decompress_wo_ec, gaussianimage_cholesky.py:161-166 / gaussianimage_rs.py:132-139):
 //   means    = tanh(float(xyz_half))
 //   cholesky = code * scale + beta, then + (0.5, 0, 0.5)       (quantize.py:86-87)
@@ -714,10 +959,51 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
     // for the aggregated form -- the scan of all boxes by every band is a chain of memory rounds)
     if (by_bands) by_bands = ws->project_agg == 3;
     if (by_bands && ensure_boxes(ws, (int64_t)frames * N) != GI2D_OK) by_bands = false;
-    if (agg) agg = !by_bands && (ws->project_agg == 1 || (ws->project_agg == 0 && frames >= 4));
+    // cells: single large frames (buckets of N entries per cell: the cell side grows until the
+    // cells fit their limits; a workspace that must not allocate never takes this form)
+    CellGrid cells = CellGrid();
+    bool by_cells = fill && !codec && frames == 1 && tiles_x < 256 && tiles_y < 256 &&
+                    !ws->fixed_memory &&
+                    (ws->project_agg == 4 ||
+                     (ws->project_agg == 0 && a.tiles_per_frame >= GI2D_CELLS_MIN_TILES &&
+                      N >= GI2D_CELLS_MIN_GAUSSIANS));
+    if (by_cells) {
+        const int rows = ws->pre_r1 - ws->pre_r0;
+        // cells of 8 x 8 tiles (4 x 4 for small frames, so that there are several), larger
+        // while there would be too many of them or their buckets would not fit
+        int k = cdiv(tiles_x, 8) * cdiv(rows, 8) >= 128 ? 3 : 2;
+        for (; k <= CELL_MAX_LOG2; ++k) {
+            cells.cells_x = cdiv(tiles_x, 1 << k);
+            cells.cells = cells.cells_x * cdiv(rows, 1 << k);
+            if (cells.cells <= CELL_MAX &&
+                (int64_t)cells.cells * N * (int64_t)sizeof(int2) <= GI2D_CELLS_MAX_BYTES)
+                break;
+        }
+        by_cells = k <= CELL_MAX_LOG2 && ensure_cells(ws, cells.cells, N) == GI2D_OK;
+        cells.log2_side = k;
+        cells.row0 = ws->pre_r0;
+        cells.row1 = ws->pre_r1;
+        cells.count = ws->d_cell_count;
+        cells.bucket = reinterpret_cast<int2 *>(ws->d_cell_bucket);
+        cells.cap = N;
+    }
+    if (by_cells) by_bands = false;
+    if (agg) agg = !by_bands && !by_cells &&
+                   (ws->project_agg == 1 || (ws->project_agg == 0 && frames >= 4));
     {
     Probe probe(fill ? ws : nullptr, GI2D_PROBE_PROJECT, st);
-    if (by_bands) {
+    if (by_cells) {
+        const dim3 cgrid(cdiv(N, CELL_THREADS));
+#define GI2D_CELLS(RS, RAW) \
+    project_cells_fwd_kernel<RS, RAW><<<cgrid, CELL_THREADS, 0, st>>>(means, cov_a, cov_b, a, cells)
+        if (kind == 0 && raw) GI2D_CELLS(false, true);
+        else if (kind == 0) GI2D_CELLS(false, false);
+        else if (raw) GI2D_CELLS(true, true);
+        else GI2D_CELLS(true, false);
+#undef GI2D_CELLS
+        fill_cells_kernel<<<cells.cells, CELL_THREADS, 0, st>>>(cells, tiles_x, a.lists.tile_count,
+                                                               a.lists.seg, a.lists.C);
+    } else if (by_bands) {
         if (kind == 0)
             project_boxes_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, cov_b, a, ws->d_box);
         else

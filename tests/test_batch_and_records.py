@@ -155,7 +155,10 @@ def test_records_change_no_bit_of_a_fit_or_a_decode(kind):
                                              ("rs", 5, 30000, 512, 768, 1.0),
                                              ("cholesky", 3, 4000, 700, 40, 3.0),
                                              ("cholesky", 1, 8192, 512, 512, 20.0),
-                                             ("rs", 2, 3000, 256, 256, 6.0)])
+                                             ("rs", 2, 3000, 256, 256, 6.0),
+                                             ("cholesky", 1, 40000, 1000, 1500, 1.0),
+                                             ("rs", 1, 5000, 300, 200, 20.0),
+                                             ("cholesky", 1, 2500, 2100, 40, 2.0)])
 def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
     """The projection that counts its tiles in LDS (one counter atomic per tile a workgroup
     touches) and the one that fills the lists by bands of tile rows (no counter atomics) against
@@ -164,7 +167,9 @@ def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
     floor of the first, beyond the limit of the second), for a frame smaller than one workgroup
     for a tall frame whose bands hold several tile rows, and for footprints so large that a
     workgroup's (tile, Gaussian) pairs exceed what it can gather in LDS (8192 Gaussians, ~20
-    tiles each) or nearly do."""
+    tiles each) or nearly do.  Form 4 (through cells of tiles, single frames): several hundred
+    cells, footprints over many cells (more pairs than either pass gathers in LDS), a frame one
+    cell wide."""
     from gaussianimage_amd import _lib
     from gaussianimage_amd.pipeline import FrameBatch
     per = [_inputs(kind, N, 30 + f, fp) for f in range(F)]
@@ -172,7 +177,7 @@ def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
              torch.stack([p[k].reshape(N, -1) for p in per]).to(DEV).contiguous() for k in range(5)]
     stack[4] = stack[4].reshape(F, N)
     got = []
-    for mode in (2, 1, 3):
+    for mode in (2, 1, 3, 4):
         b = FrameBatch(F, N, H, W, kind=kind, device=DEV)
         _lib.check(_lib.lib.gi2d_workspace_set_option(b.ws.handle, _lib.OPT_PROJECT_AGG, mode),
                    "set_option")

@@ -398,11 +398,14 @@ def test_4k_frame_properties(ops, oracle):
     assert np.abs(_np(a[:Hb]) - ref)[ok].max() <= IMG_ATOL
 
 
+@pytest.mark.parametrize("form", [0, 4])
 @pytest.mark.parametrize("kind", ["cholesky", "rs"])
-def test_tile_row_bands_equal_the_unsharded_frame(ops, oracle, kind):
+def test_tile_row_bands_equal_the_unsharded_frame(ops, oracle, kind, form):
     """Tile-row sharding on one device: every rank's band, rendered in turn, is bit-identical to
     the same rows of the unsharded frame (same lists, same order), and the per-band partial
-    gradients sum to the unsharded gradients."""
+    gradients sum to the unsharded gradients.  form 4: the bands fill their lists through cells
+    of tiles (the form large frames take by themselves), the unsharded frame does not."""
+    from gaussianimage_amd import _lib
     from gaussianimage_amd.pipeline import FramePipeline
     from gaussianimage_amd.sharding import band_pixels, band_plan
     H, W, N = 200, 176, 4000
@@ -422,6 +425,8 @@ def test_tile_row_bands_equal_the_unsharded_frame(ops, oracle, kind):
         sums = None
         for rank in range(world):
             pipe = FramePipeline(N, H, W, kind=kind, device=DEV, rows=plan[rank])
+            _lib.check(_lib.lib.gi2d_workspace_set_option(pipe.ws.handle, _lib.OPT_PROJECT_AGG,
+                                                          form), "set_option")
             y0, y1 = band_pixels(plan, rank, H)
             band = pipe.forward(*args)
             assert band.shape == (y1 - y0, W, 3)
