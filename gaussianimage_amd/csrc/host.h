@@ -129,10 +129,13 @@ struct ExtraSets {
 // 768x512 / 30k (1536 tiles, ~48 per tile) 10 / 11.5 / 18 us.
 #define GI2D_PPL2_MIN_TILES 12288
 // List filling through cells of tiles (project.hip): frames from this size on take it by
-// themselves; the buckets (cells x N entries of 8 bytes) may take this much memory.
+// themselves -- its two launches are ~20 us of mostly fixed latencies at 200 000 Gaussians,
+// one returning atomic per (Gaussian, tile) pair costs 4 us + pairs / 2e10 per second, and a
+// Gaussian of the initial footprint has ~2.5 pairs (Gaussians: those a band of tile rows can
+// expect to list); the buckets (cells x N entries of 8 bytes) may take this much memory.
 #define GI2D_CELLS_MAX 1024
 #define GI2D_CELLS_MIN_TILES 8192
-#define GI2D_CELLS_MIN_GAUSSIANS 32768
+#define GI2D_CELLS_MIN_GAUSSIANS 131072
 #define GI2D_CELLS_MAX_BYTES ((int64_t)1 << 30)
 #define GI2D_PPL4_MIN_TILES 20480
 

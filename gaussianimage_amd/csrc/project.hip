@@ -966,7 +966,7 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
                     !ws->fixed_memory &&
                     (ws->project_agg == 4 ||
                      (ws->project_agg == 0 && a.tiles_per_frame >= GI2D_CELLS_MIN_TILES &&
-                      N >= GI2D_CELLS_MIN_GAUSSIANS));
+                      (int64_t)N * (ws->pre_r1 - ws->pre_r0) / tiles_y >= GI2D_CELLS_MIN_GAUSSIANS));
     if (by_cells) {
         const int rows = ws->pre_r1 - ws->pre_r0;
         // cells of 8 x 8 tiles (4 x 4 for small frames, so that there are several), larger

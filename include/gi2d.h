@@ -99,8 +99,8 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
  * workgroup per cell, owns the cell's tiles -- no atomic on any tile counter, for large frames
  * whose Gaussians are in no spatial order (buckets: cells x N x 8 bytes of workspace memory, at
  * most 1 GiB); 0 (default) = form 1 for batches of four frames and more, form 4 for single
- * frames of at least 8192 tiles and 32 768 Gaussians, form 2 otherwise.  A tuning knob: the
- * lists are the same. */
+ * frames (or bands of tile rows) of at least 8192 tiles and 131 072 Gaussians, form 2
+ * otherwise.  A tuning knob: the lists are the same. */
 #define GI2D_OPT_PROJECT_AGG 6
 /* GI2D_OPT_BWD_SERIAL (testing aid): positions the counter of backward launches, from which
  * the stamps of the backward's partial sums derive (1 .. INT_MAX, then the slots are cleared
