@@ -149,6 +149,16 @@ static inline bool sparse_frame(const gi2d_workspace *ws, int T)
     return T >= GI2D_PPL4_MIN_TILES && ws->h_status[0] <= 64;
 }
 
+// Whether a single frame's projection fills the lists (tile rows r0 .. r1) through cells.
+static inline bool cells_form(const gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int r0,
+                              int r1)
+{
+    if (ws->fixed_memory || tiles_x >= 256 || tiles_y >= 256 || r1 <= r0) return false;
+    if (ws->project_agg == 4) return true;
+    return ws->project_agg == 0 && tiles_x * (r1 - r0) >= GI2D_CELLS_MIN_TILES &&
+           (int64_t)N * (r1 - r0) / tiles_y >= GI2D_CELLS_MIN_GAUSSIANS;
+}
+
 // tile lists of the current binning: all frames / one frame
 static inline int ws_tiles_per_frame(const gi2d_workspace *ws)
 {

@@ -962,11 +962,8 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
     // cells: single large frames (buckets of N entries per cell: the cell side grows until the
     // cells fit their limits; a workspace that must not allocate never takes this form)
     CellGrid cells = CellGrid();
-    bool by_cells = fill && !codec && frames == 1 && tiles_x < 256 && tiles_y < 256 &&
-                    !ws->fixed_memory &&
-                    (ws->project_agg == 4 ||
-                     (ws->project_agg == 0 && a.tiles_per_frame >= GI2D_CELLS_MIN_TILES &&
-                      (int64_t)N * (ws->pre_r1 - ws->pre_r0) / tiles_y >= GI2D_CELLS_MIN_GAUSSIANS));
+    bool by_cells = fill && !codec && frames == 1 &&
+                    cells_form(ws, N, tiles_x, tiles_y, ws->pre_r0, ws->pre_r1);
     if (by_cells) {
         const int rows = ws->pre_r1 - ws->pre_r0;
         // cells of 8 x 8 tiles (4 x 4 for small frames, so that there are several), larger

@@ -157,6 +157,39 @@ def test_chained_and_one_pass_steps_are_the_plain_step(kind, N, ppl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cholesky", "rs"])
+def test_fit_whose_projection_fills_the_lists_through_cells_is_the_plain_fit(kind):
+    """Large frames project with a launch pair of their own (lists through cells of tiles)
+    instead of inside the tail: forced on a small frame, it leaves the bits of the default
+    step -- parameters, optimizer state, losses, image."""
+    from gaussianimage_amd import _lib
+    from gaussianimage_amd.fit import FusedFitter
+    N, H, W = 5000, 160, 208
+    gt = synth.target_image(H, W).to(DEV)
+    fits = []
+    for form in (0, 4):
+        torch.manual_seed(11)
+        f = FusedFitter(N, H, W, kind=kind, device=DEV)
+        _lib.check(_lib.lib.gi2d_workspace_set_option(f.ws.handle, _lib.OPT_PROJECT_AGG, form),
+                   "set_option")
+        fits.append(f)
+    losses = [[], []]
+    for it in range(7):
+        for k, f in enumerate(fits):
+            f.step(gt)
+            losses[k].append(f.loss())
+    assert losses[0] == losses[1]
+    a, b = fits
+    for k in a.params:
+        assert torch.equal(a.params[k], b.params[k]), k
+        for s in a.state[k]:
+            assert torch.equal(a.state[k][s], b.state[k][s]), (k, s)
+    for f in fits:
+        f.forward(gt)
+    assert torch.equal(a.image, b.image) and torch.equal(a.xys, b.xys)
+
+
+@pytest.mark.gpu
 def test_one_pass_step_keeps_the_image_and_survives_forward_calls_in_between():
     """gi2d_fit_step writes the optional image like the forward does, and explicit forward()
     calls between steps (which consume the lists the chained tail prepared) change nothing."""
