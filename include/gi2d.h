@@ -347,6 +347,9 @@ int gi2d_fit_backward_step_chain(gi2d_workspace *ws, int kind, float *xyz, float
  * alone, so a tile that has rendered goes straight on to its backward pass:
  * the loss gradient stays on chip (there is no v_image), the tile's sorted
  * list is used twice.  Same arithmetic, same results as the two calls.
+ * (Frames large enough to fill their lists through cells of tiles, see
+ * GI2D_OPT_PROJECT_AGG, project with that launch pair instead of inside the
+ * tail: four launches.)
  * image[H,W,3] optional (NULL to skip); loss_partials[tiles] as above.  Returns
  * as gi2d_fit_forward does (GI2D_E_PREV_OVERFLOW = this iteration is complete,
  * an earlier one lost some tiles).  No counterpart in the reference (its loop
