@@ -158,7 +158,8 @@ def test_records_change_no_bit_of_a_fit_or_a_decode(kind):
                                              ("rs", 2, 3000, 256, 256, 6.0),
                                              ("cholesky", 1, 40000, 1000, 1500, 1.0),
                                              ("rs", 1, 5000, 300, 200, 20.0),
-                                             ("cholesky", 1, 2500, 2100, 40, 2.0)])
+                                             ("cholesky", 1, 2500, 2100, 40, 2.0),
+                                             ("cholesky", 1, 2048, 512, 512, 60.0)])
 def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
     """The projection that counts its tiles in LDS (one counter atomic per tile a workgroup
     touches) and the one that fills the lists by bands of tile rows (no counter atomics) against
@@ -191,6 +192,8 @@ def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
             assert torch.equal(x, y)
     if fp == 20.0:   # (8 workgroups of 1024 Gaussians, 16384 pairs gathered at most)
         assert int(got[0][1][-1]) > 8 * 16384
+    if fp == 60.0:   # (2 workgroups, hundreds of tiles per Gaussian)
+        assert int(got[0][1][-1]) > 2 * 16 * 16384
 
 
 @pytest.mark.parametrize("depth", [1, 2, 3])
