@@ -48,8 +48,9 @@ struct gi2d_workspace {
     int *d_box = nullptr;            // packed tile boxes of the band-wise list filling
     int64_t box_cap = 0;
     // list filling through cells (large frames): per-cell counters and buckets
-    int *d_cell_count = nullptr;     // [GI2D_CELLS_MAX][CNT_STRIDE], zero between frames
-    void *d_cell_bucket = nullptr;   // [cells][N] (id, packed box)
+    int *d_cell_count = nullptr;     // [frames x cells][CNT_STRIDE], zero between calls
+    int64_t cell_count_cap = 0;      // cells the counters are allocated for
+    void *d_cell_bucket = nullptr;   // [frames x cells][N] (id, packed box)
     int64_t cell_bucket_cap = 0;     // entries the buckets hold in all
     bool fixed_memory = false;       // the workspace lives in memory that cannot grow
     int no_records = 0;  // 1: projections never write the rasteriser's records (no-alloc path)
@@ -135,6 +136,7 @@ struct ExtraSets {
 // expect to list); the buckets (cells x N entries of 8 bytes) may take this much memory.
 #define GI2D_CELLS_MAX 1024
 #define GI2D_CELLS_MIN_TILES 8192
+#define GI2D_CELLS_MIN_TILES_BATCH 2048
 #define GI2D_CELLS_MIN_GAUSSIANS 131072
 #define GI2D_CELLS_MAX_BYTES ((int64_t)1 << 30)
 #define GI2D_PPL4_MIN_TILES 20480
@@ -151,11 +153,21 @@ static inline bool sparse_frame(const gi2d_workspace *ws, int T)
 
 // Whether a single frame's projection fills the lists (tile rows r0 .. r1) through cells.
 static inline bool cells_form(const gi2d_workspace *ws, int N, int tiles_x, int tiles_y, int r0,
-                              int r1)
+                              int r1, int frames = 1)
 {
     if (ws->fixed_memory || tiles_x >= 256 || tiles_y >= 256 || r1 <= r0) return false;
     if (ws->project_agg == 4) return true;
-    return ws->project_agg == 0 && tiles_x * (r1 - r0) >= GI2D_CELLS_MIN_TILES &&
+    if (ws->project_agg != 0) return false;
+    // batches (which otherwise aggregate per workgroup in LDS): frames of many tiles -- every
+    // workgroup of the aggregated form pays one counter atomic per tile -- or of long lists --
+    // its pairs no longer fit the stage.  Measured per 24 frames: 1020x768 / 50 000 (3072 tiles)
+    // 59.5 us against 81.8 us, 768x512 / 30 000 with three times the footprint (lists of up to
+    // 300) 39.4 against 51.6 us, but 768x512 / 30 000 as initialised 32.2 against 30.9 us and
+    // 768x512 / 5 000 27.8 against 14.9 us.
+    if (frames != 1)
+        return frames >= 4 && (tiles_x * (r1 - r0) >= GI2D_CELLS_MIN_TILES_BATCH ||
+                               ws->h_status[0] > 128);
+    return tiles_x * (r1 - r0) >= GI2D_CELLS_MIN_TILES &&
            (int64_t)N * (r1 - r0) / tiles_y >= GI2D_CELLS_MIN_GAUSSIANS;
 }
 
@@ -170,7 +182,7 @@ static inline int ws_tiles(const gi2d_workspace *ws) { return ws->frames * ws_ti
 int ensure_lists(gi2d_workspace *ws, int T, int C);
 int ensure_records(gi2d_workspace *ws, int64_t count);
 int ensure_boxes(gi2d_workspace *ws, int64_t count);
-int ensure_cells(gi2d_workspace *ws, int cells, int N);
+int ensure_cells(gi2d_workspace *ws, int64_t cells, int N);
 int bin_tiles_impl(gi2d_workspace *ws, const float *xys, const int *radii, int N, int tiles_x,
                    int tiles_y, int flags, void *stream, int frames);
 int wanted_cap(const gi2d_workspace *ws, long long seen);

@@ -184,16 +184,23 @@ int ensure_records(gi2d_workspace *ws, int64_t count)
     return GI2D_OK;
 }
 
-// Counters and buckets of `cells` cells of N entries each; the device is current.
-int ensure_cells(gi2d_workspace *ws, int cells, int N)
+// Counters and buckets of `cells` cells (of all frames of a batch) of N entries each; the
+// device is current.
+int ensure_cells(gi2d_workspace *ws, int64_t cells, int N)
 {
-    if (cells < 1 || cells > GI2D_CELLS_MAX) return GI2D_E_INVALID;
-    if (!ws->d_cell_count) {
-        const size_t bytes = sizeof(int) * (size_t)GI2D_CELLS_MAX * CNT_STRIDE;
+    if (cells < 1) return GI2D_E_INVALID;
+    if (ws->cell_count_cap < cells) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (ws->d_cell_count) (void)hipFree(ws->d_cell_count);
+        ws->d_cell_count = nullptr;
+        ws->cell_count_cap = 0;
+        const size_t bytes = sizeof(int) * (size_t)cells * CNT_STRIDE;
         HIP_TRY(hipMalloc(&ws->d_cell_count, bytes));
         HIP_TRY(hipMemset(ws->d_cell_count, 0, bytes));
+        HIP_TRY(hipDeviceSynchronize());  // (null-stream clear, see ensure_lists)
+        ws->cell_count_cap = cells;
     }
-    const int64_t want = (int64_t)cells * N;
+    const int64_t want = cells * N;
     if (ws->cell_bucket_cap >= want) return GI2D_OK;
     HIP_TRY(hipDeviceSynchronize());
     if (ws->d_cell_bucket) (void)hipFree(ws->d_cell_bucket);

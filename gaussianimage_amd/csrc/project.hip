@@ -478,8 +478,8 @@ struct CellGrid {
     int log2_side;      // a cell is 2^log2_side tiles wide and high
     int cells_x, cells;
     int row0, row1;     // the tile rows the lists cover
-    int *count;         // [cells][CNT_STRIDE], zero between frames
-    int2 *bucket;       // [cells][cap]: (Gaussian id, x0 | x1 << 8 | y0 << 16 | y1 << 24)
+    int *count;         // [frames][cells][CNT_STRIDE], zero between calls
+    int2 *bucket;       // [frames][cells][cap]: (Gaussian id, x0 | x1 << 8 | y0 << 16 | y1 << 24)
     int cap;
 };
 
@@ -514,9 +514,15 @@ __global__ __launch_bounds__(CELL_THREADS) void project_cells_fwd_kernel(
     __shared__ int chist[CELL_MAX];
     __shared__ int2 stage[CELL_STAGE1];
     __shared__ int wave_sum[CELL_THREADS / 64];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, f = blockIdx.y;
     const int g = blockIdx.x * CELL_THREADS + tid;
-    if (g == 0) publish_status(a.status, a.h_status, a.generation);
+    if (g == 0 && f == 0) publish_status(a.status, a.h_status, a.generation);
+    to_frame(a, f);
+    means += (size_t)f * 2 * a.N;
+    cov_a += (size_t)f * (RS ? 2 : 3) * a.N;
+    if (RS) cov_b += (size_t)f * a.N;
+    cg.count += (size_t)f * cg.cells * CNT_STRIDE;
+    cg.bucket += (size_t)f * cg.cells * cg.cap;
     chist[tid] = 0;
     __syncthreads();
     int packed = 0, cx0 = 0, cx1 = 0, cy0 = 0, cy1 = 0;  // the box, and the cells it touches
@@ -621,7 +627,14 @@ __global__ __launch_bounds__(CELL_THREADS) void fill_cells_kernel(
     __shared__ int stage[CELL_STAGE2];
     __shared__ unsigned short owner[CELL_STAGE2];
     __shared__ int wave_sum[CELL_THREADS / 64];
-    const int tid = threadIdx.x, c = blockIdx.x;
+    const int tid = threadIdx.x, c = blockIdx.x, f = blockIdx.y;
+    {
+        const size_t T = (size_t)tiles_x * (cg.row1 - cg.row0);  // tile lists per frame
+        tile_count += f * T * CNT_STRIDE;
+        seg += f * T * C;
+        cg.count += (size_t)f * cg.cells * CNT_STRIDE;
+        cg.bucket += (size_t)f * cg.cells * cg.cap;
+    }
     const int n = min(cg.count[(size_t)c * CNT_STRIDE], cg.cap);
     hist[tid] = 0;
     __syncthreads();  // (every lane has read the counter)
@@ -962,21 +975,22 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
     // cells: single large frames (buckets of N entries per cell: the cell side grows until the
     // cells fit their limits; a workspace that must not allocate never takes this form)
     CellGrid cells = CellGrid();
-    bool by_cells = fill && !codec && frames == 1 &&
-                    cells_form(ws, N, tiles_x, tiles_y, ws->pre_r0, ws->pre_r1);
+    bool by_cells = fill && !codec &&
+                    cells_form(ws, N, tiles_x, tiles_y, ws->pre_r0, ws->pre_r1, frames);
     if (by_cells) {
         const int rows = ws->pre_r1 - ws->pre_r0;
         // cells of 8 x 8 tiles (4 x 4 for small frames, so that there are several), larger
         // while there would be too many of them or their buckets would not fit
-        int k = cdiv(tiles_x, 8) * cdiv(rows, 8) >= 128 ? 3 : 2;
+        int k = (int64_t)frames * cdiv(tiles_x, 8) * cdiv(rows, 8) >= 128 ? 3 : 2;
         for (; k <= CELL_MAX_LOG2; ++k) {
             cells.cells_x = cdiv(tiles_x, 1 << k);
             cells.cells = cells.cells_x * cdiv(rows, 1 << k);
             if (cells.cells <= CELL_MAX &&
-                (int64_t)cells.cells * N * (int64_t)sizeof(int2) <= GI2D_CELLS_MAX_BYTES)
+                (int64_t)frames * cells.cells * N * (int64_t)sizeof(int2) <= GI2D_CELLS_MAX_BYTES)
                 break;
         }
-        by_cells = k <= CELL_MAX_LOG2 && ensure_cells(ws, cells.cells, N) == GI2D_OK;
+        by_cells = k <= CELL_MAX_LOG2 &&
+                   ensure_cells(ws, (int64_t)frames * cells.cells, N) == GI2D_OK;
         cells.log2_side = k;
         cells.row0 = ws->pre_r0;
         cells.row1 = ws->pre_r1;
@@ -990,7 +1004,7 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
     {
     Probe probe(fill ? ws : nullptr, GI2D_PROBE_PROJECT, st);
     if (by_cells) {
-        const dim3 cgrid(cdiv(N, CELL_THREADS));
+        const dim3 cgrid(cdiv(N, CELL_THREADS), frames);
 #define GI2D_CELLS(RS, RAW) \
     project_cells_fwd_kernel<RS, RAW><<<cgrid, CELL_THREADS, 0, st>>>(means, cov_a, cov_b, a, cells)
         if (kind == 0 && raw) GI2D_CELLS(false, true);
@@ -998,8 +1012,8 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
         else if (raw) GI2D_CELLS(true, true);
         else GI2D_CELLS(true, false);
 #undef GI2D_CELLS
-        fill_cells_kernel<<<cells.cells, CELL_THREADS, 0, st>>>(cells, tiles_x, a.lists.tile_count,
-                                                               a.lists.seg, a.lists.C);
+        fill_cells_kernel<<<dim3(cells.cells, frames), CELL_THREADS, 0, st>>>(
+            cells, tiles_x, a.lists.tile_count, a.lists.seg, a.lists.C);
     } else if (by_bands) {
         if (kind == 0)
             project_boxes_fwd_kernel<false><<<grid, block, 0, st>>>(means, cov_a, cov_b, a, ws->d_box);

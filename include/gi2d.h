@@ -94,13 +94,14 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
  * counter atomic per (Gaussian, tile) pair; 3 = by bands of tile rows: the projection leaves a
  * packed tile box per Gaussian and a second launch, one workgroup per (band, frame), owns the
  * band's tiles and needs no counter atomics (frames of at most 65 536 Gaussians; two launches,
- * measured slower than form 1 at 8 x 30 000 Gaussians); 4 = through cells of tiles (single
- * frames): the projection sorts (id, tile box) into per-cell buckets, a second launch, one
- * workgroup per cell, owns the cell's tiles -- no atomic on any tile counter, for large frames
- * whose Gaussians are in no spatial order (buckets: cells x N x 8 bytes of workspace memory, at
- * most 1 GiB); 0 (default) = form 1 for batches of four frames and more, form 4 for single
- * frames (or bands of tile rows) of at least 8192 tiles and 131 072 Gaussians, form 2
- * otherwise.  A tuning knob: the lists are the same. */
+ * measured slower than form 1 at 8 x 30 000 Gaussians); 4 = through cells of tiles: the
+ * projection sorts (id, tile box) into per-cell buckets, a second launch, one workgroup per
+ * (cell, frame), owns the cell's tiles -- no atomic on any tile counter, for frames of many
+ * tiles whose Gaussians are in no spatial order (buckets: frames x cells x N x 8 bytes of
+ * workspace memory, at most 1 GiB); 0 (default) = for batches of four frames and more form 4
+ * when a frame has at least 2048 tiles or lists have been longer than 128, else form 1; for
+ * single frames (or bands of tile rows) form 4 from 8192 tiles and 131 072 Gaussians, else
+ * form 2.  A tuning knob: the lists are the same. */
 #define GI2D_OPT_PROJECT_AGG 6
 /* GI2D_OPT_BWD_SERIAL (testing aid): positions the counter of backward launches, from which
  * the stamps of the backward's partial sums derive (1 .. INT_MAX, then the slots are cleared
