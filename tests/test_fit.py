@@ -366,13 +366,18 @@ def test_sharded_fit_on_one_device_follows_the_unsharded_fit(kind, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,F,N,H,W,K", [("cholesky", 3, 1500, 96, 128, 25),
-                                            ("rs", 2, 1200, 80, 112, 25),
-                                            ("cholesky", 5, 30000, 512, 768, 12)])
-def test_batch_fitter_gives_every_image_its_own_fit(kind, F, N, H, W, K):
+@pytest.mark.parametrize("kind,F,N,H,W,K,form", [("cholesky", 3, 1500, 96, 128, 25, 0),
+                                                 ("rs", 2, 1200, 80, 112, 25, 0),
+                                                 ("cholesky", 5, 30000, 512, 768, 12, 0),
+                                                 ("rs", 4, 2500, 160, 208, 12, 4),
+                                                 ("cholesky", 2, 3000, 144, 240, 12, 4)])
+def test_batch_fitter_gives_every_image_its_own_fit(kind, F, N, H, W, K, form):
     """F images fitted in lockstep by one call of two launches: image f's parameters, optimizer
     state and losses are, bit for bit, those of a FusedFitter that fits it alone -- also across
-    an outside edit of the parameters (the chained projection is dropped and redone)."""
+    an outside edit of the parameters (the chained projection is dropped and redone).  form 4:
+    the batch fills its lists through cells of tiles (as batches of large frames do by
+    themselves), the single fits do not."""
+    from gaussianimage_amd import _lib
     from gaussianimage_amd.fit import BatchFitter, FusedFitter
     per = []
     for f in range(F):
@@ -387,6 +392,8 @@ def test_batch_fitter_gives_every_image_its_own_fit(kind, F, N, H, W, K):
                for p in per]
     batch = BatchFitter(F, N, H, W, kind=kind, device=DEV, lr=5e-3,
                         params={k: torch.stack([p[k] for p in per]) for k in per[0]})
+    _lib.check(_lib.lib.gi2d_workspace_set_option(batch.ws.handle, _lib.OPT_PROJECT_AGG, form),
+               "set_option")
     for it in range(K):
         if it == K // 2:
             # an edit from outside between two iterations
