@@ -370,7 +370,10 @@ int gi2d_fit_step(gi2d_workspace *ws, int kind, float *xyz, float *cov_a, float 
  * and per-Gaussian tensor is [frames][N][...] (the four state arrays hold one pointer per
  * parameter tensor, as in gi2d_fit_step), gt_chw is [frames][3][H][W], images (optional)
  * [frames][H][W][3], loss_partials [frames][tiles].  Image f's parameters after the call are
- * bit-identical to gi2d_fit_step's on slice f.  The reference fits the images of a dataset one
+ * bit-identical to gi2d_fit_step's on slice f when both run the same workgroup shape
+ * (GI2D_OPT_RASTER_PPL; left to itself a batch of many tiles takes one wave per tile where a
+ * single 768x512 image takes four, and the backward then adds a Gaussian's per-pixel terms in
+ * another order: last-bit differences in the gradients).  The reference fits the images of a dataset one
  * after the other (/root/reference/train.py:366-372); one 768x512 fit leaves most of the chip
  * idle, a batch fills it.  Whole frames only.  No counterpart in the reference. */
 int gi2d_fit_step_batch(gi2d_workspace *ws, int kind, int frames, float *xyz, float *cov_a,

@@ -419,6 +419,36 @@ def test_batch_fitter_gives_every_image_its_own_fit(kind, F, N, H, W, K, form):
 
 
 @pytest.mark.gpu
+def test_batch_of_24_at_full_size_is_the_single_fit_of_the_same_workgroup_shape():
+    """24 images of 768x512 / 30 000 Gaussians in one call: the batch takes one wave per tile
+    (36 864 tiles in the launch); single fits forced to that shape leave the same bits.  (Left
+    to its own four waves per tile a single fit adds a Gaussian's per-pixel gradient terms in
+    another order and agrees only to rounding.)"""
+    from gaussianimage_amd.fit import BatchFitter, FusedFitter
+    F, N, H, W = 24, 30000, 512, 768
+    per = []
+    for f in range(F):
+        xyz, chol, feat = synth.cholesky_params(N, seed=40 + f)
+        per.append({"_xyz": xyz, "_cholesky": chol, "_features_dc": feat})
+    gts = torch.stack([synth.target_image(H, W, seed=f)[0] for f in range(F)]).to(DEV).contiguous()
+    batch = BatchFitter(F, N, H, W, kind="cholesky", device=DEV, lr=5e-3,
+                        params={k: torch.stack([p[k] for p in per]) for k in per[0]})
+    picks = (0, 11, 23)
+    singles = {f: FusedFitter(N, H, W, kind="cholesky", device=DEV, lr=5e-3, params=per[f],
+                              keep_image=False) for f in picks}
+    for s in singles.values():
+        s.ws.set_raster_ppl(4)
+    for it in range(5):
+        for f, s in singles.items():
+            s.step(gts[f:f + 1])
+        batch.step(gts)
+    for f, s in singles.items():
+        assert torch.equal(batch.loss_partials[f], s.loss_partials), f
+        for k in s.params:
+            assert torch.equal(batch.params[k][f], s.params[k]), (f, k)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("F", [2, 5])
 def test_growing_gaussians_do_not_stop_a_batch_fit(F):
     """The batch fit under the same stress as the single fit: footprints that outgrow the lists'
