@@ -201,6 +201,8 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
 // work-piece buffers
 #define FIT_POOL_BWD_INTS \
     (3 * 4 * BWD_BATCH + (BWD_BATCH + 4) + BWD_MAX_PIECES * PART_STRIDE + BWD_MAX_PIECES / 4)
+// ... of the one-wave form (32 entries per batch, 64 pieces)
+#define FIT64_POOL_BWD_INTS (3 * 4 * 32 + (32 + 4) + 64 * PART_STRIDE + 64 / 4)
 
 // The backward of one tile inside the fused kernel, workgroup of 256 lanes: direct paths for
 // short lists, equal work pieces beyond.
@@ -253,9 +255,25 @@ __device__ __forceinline__ void fit_bwd_64(
     bwd_tile<LPE, 64>(lst, s_first, n_raw, slot0, tx, ty, s_v, xys, radii, conics, colors,       \
                       opacity, H, W, tiles_x, tiles_y, row0, cv, cull, partials, gslots, gslot_n, \
                       stamp)
-    if (n_raw <= 4) GI2D_BWD_TILE(16);
-    else if (n_raw <= 8) GI2D_BWD_TILE(8);
-    else GI2D_BWD_TILE(4);
+    if (n_raw <= 4) {
+        GI2D_BWD_TILE(16);
+    } else if (n_raw <= 8) {
+        GI2D_BWD_TILE(8);
+    } else if (n_raw <= BWD64_PIECES_MIN_LIST) {
+        GI2D_BWD_TILE(4);
+    } else {
+        // longer lists: equal work pieces, as in the 256-lane form (with four lanes per entry
+        // every batch of 16 entries lasts as long as its largest entry)
+        __syncthreads();  // (s_first is about to be overwritten)
+        float4 *s_r0 = reinterpret_cast<float4 *>(pool);
+        float4 *s_r1 = s_r0 + 32, *s_r2 = s_r1 + 32;
+        int *s_start = reinterpret_cast<int *>(s_r2 + 32);
+        float *s_piece = reinterpret_cast<float *>(s_start + 32 + 4);
+        unsigned char *s_owner = reinterpret_cast<unsigned char *>(s_piece + 64 * PART_STRIDE);
+        bwd_tile_pieces<64>(lst, gid_first, n_raw, slot0, tx, ty, s_v, s_r0, s_r1, s_r2, s_start,
+                            nullptr, s_piece, s_owner, xys, radii, conics, colors, opacity, H, W,
+                            tiles_x, tiles_y, row0, cv, cull, partials, gslots, gslot_n, stamp);
+    }
 #undef GI2D_BWD_TILE
 }
 
@@ -301,7 +319,7 @@ fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *
     // records, in a part the backward writes only after every lane has fetched its id
     constexpr int POOL_INTS =
         PPL == 1 ? (FIT_POOL_BWD_INTS > FWD_INTS + NT ? FIT_POOL_BWD_INTS : FWD_INTS + NT)
-                 : FWD_INTS + NT;
+                 : (FIT64_POOL_BWD_INTS > FWD_INTS + NT ? FIT64_POOL_BWD_INTS : FWD_INTS + NT);
     __shared__ __attribute__((aligned(16))) int pool[POOL_INTS];
     __shared__ float4 s_v[256];   // the tile's loss gradient
     __shared__ int s_w[4];

@@ -83,8 +83,9 @@ rasterize_sum_bwd_kernel(
 }
 
 // The same for sparse frames (many tiles with a handful of Gaussians each): ONE wave per tile,
-// each entry gets 4 to 16 lanes, no work-piece path.  Per tile it spends about half the
-// instructions of the 256-lane form, whose four waves all pay the per-entry set-up.
+// each entry gets 4 to 16 lanes; lists beyond 16 entries are cut into work pieces.  Per tile it
+// spends about half the instructions of the 256-lane form, whose four waves all pay the
+// per-entry set-up.
 __global__ __launch_bounds__(64) void rasterize_sum_bwd_wave_kernel(
     const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
     const float *__restrict__ xys, const int *__restrict__ radii,
@@ -95,6 +96,10 @@ __global__ __launch_bounds__(64) void rasterize_sum_bwd_wave_kernel(
 {
     __shared__ float4 s_v[256];
     __shared__ int s_first[64];
+    __shared__ float4 s_r0[32], s_r1[32], s_r2[32];  // the work-piece path's buffers, as above
+    __shared__ int s_start[32 + 1];
+    __shared__ float s_piece[64 * PART_STRIDE];
+    __shared__ unsigned char s_owner[64];
     const int tid = threadIdx.x;
     const int t = xcd_tile(blockIdx.x, T);
     const int *lst = seg + (size_t)t * C;
@@ -124,7 +129,11 @@ __global__ __launch_bounds__(64) void rasterize_sum_bwd_wave_kernel(
                       stamp)
     if (n_raw <= 4) GI2D_BWD_TILE(16);
     else if (n_raw <= 8) GI2D_BWD_TILE(8);
-    else GI2D_BWD_TILE(4);
+    else if (n_raw <= BWD64_PIECES_MIN_LIST) GI2D_BWD_TILE(4);
+    else
+        bwd_tile_pieces<64>(lst, gid_first, n_raw, slot0, tx, ty, s_v, s_r0, s_r1, s_r2, s_start,
+                            nullptr, s_piece, s_owner, xys, radii, conics, colors, opacity, H, W,
+                            tiles_x, tiles_y, row0, cv, cull, partials, gslots, gslot_n, stamp);
 #undef GI2D_BWD_TILE
 }
 

@@ -13,11 +13,18 @@
 #ifndef BWD_PIECES_MIN_LIST
 #define BWD_PIECES_MIN_LIST 32
 #endif
+// ... of the one-wave forms (32 entries per batch, 16 quads, 64 pieces): with four lanes per
+// entry a batch of 16 entries lasts as long as its largest entry
+#ifndef BWD64_PIECES_MIN_LIST
+#define BWD64_PIECES_MIN_LIST 16
+#endif
 #define BWD_QUADS 64                   // quads of lanes per workgroup
 #define BWD_MAX_ROUNDS 4               // rounds of BWD_QUADS pieces a batch is cut into, at most
 #define BWD_MAX_PIECES (BWD_QUADS * BWD_MAX_ROUNDS)
 
-// inclusive prefix sum over the 256 lanes of the workgroup (s_w: 4 ints of LDS); total in `all`
+// inclusive prefix sum over the NT (256 or 64) lanes of the workgroup (s_w: 4 ints of LDS, unused
+// by a single wave); total in `all`
+template <int NT = 256>
 __device__ __forceinline__ int block_inclusive_scan(int v, int *s_w, int &all)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -25,6 +32,10 @@ __device__ __forceinline__ int block_inclusive_scan(int v, int *s_w, int &all)
     for (int d = 1; d < 64; d <<= 1) {
         const int o = __shfl_up(v, d);
         if (lane >= d) v += o;
+    }
+    if (NT == 64) {
+        all = __builtin_amdgcn_readlane(v, 63);
+        return v;
     }
     __syncthreads();  // (s_w may still be read from an earlier scan)
     if (lane == 63) s_w[wave] = v;
@@ -158,7 +169,10 @@ __device__ __forceinline__ void bwd_tile(
     }
 }
 
-// The work-piece path (long lists): the batches of one tile.
+// The work-piece path (long lists): the batches of one tile, in a workgroup of NT lanes (256 or
+// 64): NT / 2 entries per batch, NT / 4 quads, at most NT pieces.  s_r0 / s_r1 / s_r2 hold NT / 2
+// float4 each, s_start NT / 2 + 1 ints, s_piece NT x PART_STRIDE floats, s_owner NT bytes.
+template <int NT = 256>
 __device__ __forceinline__ void bwd_tile_pieces(
     const int *lst, int gid_first, int n_raw, size_t slot0, int tx, int ty,
     const float4 *s_v, float4 *s_r0, float4 *s_r1, float4 *s_r2, int *s_start, int *s_w,
@@ -168,13 +182,15 @@ __device__ __forceinline__ void bwd_tile_pieces(
     const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
     size_t gslot_n, int stamp)
 {
+    constexpr int EB = NT / 2, QUADS = NT / 4, MAX_PIECES = QUADS * BWD_MAX_ROUNDS;
+    static_assert(EB == BWD_BATCH || NT == 64, "buffers are sized by BWD_BATCH for 256 lanes");
     const int tid = threadIdx.x, q = tid & 3, quad = tid >> 2;
     const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
     const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
     const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
     const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
-    for (int base = 0; base < n_raw; base += BWD_BATCH) {
-        const int n = min(BWD_BATCH, n_raw - base);
+    for (int base = 0; base < n_raw; base += EB) {
+        const int n = min(EB, n_raw - base);
         // ---- A: stage entry `tid` ----------------------------------------------------------
         int cnt = 0;
         if (tid < n) {
@@ -194,31 +210,31 @@ __device__ __forceinline__ void bwd_tile_pieces(
                                     __int_as_float(rect));
         }
         // ---- B: pieces ---------------------------------------------------------------------
-        // The batch's pixels are cut into about BWD_QUADS pieces per 32 entries (at most
-        // BWD_MAX_ROUNDS x BWD_QUADS): the quads then make that many rounds over pieces of about
+        // The batch's pixels are cut into about QUADS pieces per EB / 4 entries (at most
+        // BWD_MAX_ROUNDS x QUADS): the quads then make that many rounds over pieces of about
         // equal size.  With fewer, larger pieces a round lasts as long as its largest entry while
         // most quads hold small ones (measured on fitted-size supports: 3 rounds of ~55 pixel
         // steps for 128 entries, where 4 rounds of ~17 do).
         int total = 0;
-        (void)block_inclusive_scan(cnt, s_w, total);
-        const int rounds = min(BWD_MAX_ROUNDS, (n + 31) >> 5);
+        (void)block_inclusive_scan<NT>(cnt, s_w, total);
+        const int rounds = min(BWD_MAX_ROUNDS, (n + EB / 4 - 1) / (EB / 4));
         // expected pieces = total / chunk + n / 2 (half a piece of rounding per entry)
         int chunk = max(8, (int)((float)total * __builtin_amdgcn_rcpf(
-                                     (float)(BWD_QUADS * rounds - (n >> 1)))) + 1);
+                                     (float)(QUADS * rounds - (n >> 1)))) + 1);
         // ceil(cnt / chunk) <= 32 (cnt <= 256, chunk >= 8) from the hardware reciprocal: exact,
         // the quotient's fractional part is a multiple of 1/chunk
         float rchunk = __builtin_amdgcn_rcpf((float)chunk);
         int my_pieces = cnt ? (int)(((float)(cnt + chunk - 1) + 0.5f) * rchunk) : 0;
         int n_pieces = 0;
-        int incl = block_inclusive_scan(my_pieces, s_w, n_pieces);
-        if (n_pieces > BWD_MAX_PIECES) {
+        int incl = block_inclusive_scan<NT>(my_pieces, s_w, n_pieces);
+        if (n_pieces > MAX_PIECES) {
             // (rare: many entries just over a multiple of the chunk)  sum ceil(cnt / chunk) <=
             // total / chunk + n, so this chunk fits whatever the counts are
             chunk = max(chunk, (int)((float)total * __builtin_amdgcn_rcpf(
-                                         (float)(BWD_MAX_PIECES - n))) + 2);
+                                         (float)(MAX_PIECES - n))) + 2);
             rchunk = __builtin_amdgcn_rcpf((float)chunk);
             my_pieces = cnt ? (int)(((float)(cnt + chunk - 1) + 0.5f) * rchunk) : 0;
-            incl = block_inclusive_scan(my_pieces, s_w, n_pieces);
+            incl = block_inclusive_scan<NT>(my_pieces, s_w, n_pieces);
         }
         if (tid < n) {
             const int p0 = incl - my_pieces;
@@ -228,7 +244,7 @@ __device__ __forceinline__ void bwd_tile_pieces(
         if (tid == 0) s_start[n] = n_pieces;
         __syncthreads();
         // ---- C: a quad per piece -----------------------------------------------------------
-        for (int p = quad; p < n_pieces; p += BWD_QUADS) {
+        for (int p = quad; p < n_pieces; p += QUADS) {
             const int e = s_owner[p];
             const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
             const float gx = r0.x, gy = r0.y, a = r0.z, b = r0.w, c = r1.x, op = r1.y;
