@@ -566,7 +566,7 @@ __global__ __launch_bounds__(CELL_THREADS) void project_cells_fwd_kernel(
         TileBox box;
         const bool listed = project_body(g, mx, my, sxx, sxy, syy, a.H, a.W, a.tiles_x, a.tiles_y,
                                          a.center_bias, a.out, true, a.cull, a.rec, cr, cgr, cb,
-                                         box);
+                                         box, cg.row0, cg.row1);
         const int y0 = max(box.y0, cg.row0), y1 = min(box.y1, cg.row1);
         if (listed && box.x1 > box.x0 && y1 > y0) {
             packed = box.x0 | (box.x1 << 8) | (y0 << 16) | (y1 << 24);

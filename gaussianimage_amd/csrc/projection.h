@@ -76,12 +76,16 @@ __device__ __forceinline__ Record make_record(float cx, float cy, float ca, floa
 // Everything of a projection but the list filling: the five outputs, the record, and the tile
 // box the Gaussian is to be listed in (culled to its support when the opacities are known).
 // Returns false when it is listed nowhere.  (cr, cg, cb_): the colour that goes into the record
-// (unused without records).  want_lists: false skips the box culling.
+// (unused without records).  want_lists: false skips the box culling.  [row0, row1): the tile
+// rows the lists cover -- a Gaussian whose box lies outside them (seven of eight, for a rank that
+// owns an eighth of the frame) gets its five outputs and nothing else: no support bound, no
+// record (which only a list entry could ever refer to).
 __device__ __forceinline__ bool project_body(int g, float mx, float my, float sxx, float sxy,
                                              float syy, int H, int W, int tiles_x, int tiles_y,
                                              float center_bias, const ProjOut &o, bool want_lists,
                                              const ListCull &cull, const RecordSink &rs, float cr,
-                                             float cg, float cb_, TileBox &box)
+                                             float cg, float cb_, TileBox &box, int row0 = 0,
+                                             int row1 = INT_MAX)
 {
     float ca = 0.f, cb = 0.f, cc = 0.f, radius = 0.f, cx = 0.f, cy = 0.f;
     int irad = 0, area = 0;
@@ -105,6 +109,7 @@ __device__ __forceinline__ bool project_body(int g, float mx, float my, float sx
     o.conics[3 * g + 2] = cc;
     o.num_tiles_hit[g] = area;
     const bool listed = irad > 0 && area > 0;
+    if (listed && (box.y1 <= row0 || box.y0 >= row1)) return false;  // outside the band
     // the support bound serves the list culling and the record alike
     const float *opacity = rs.rec != nullptr ? rs.opacity : cull.opacity;
     Record rec = Record();
@@ -134,7 +139,8 @@ __device__ __forceinline__ void project_tail(int g, float mx, float my, float sx
     TileBox box;
     const bool fill = tl.tile_count != nullptr;
     const bool listed = project_body(g, mx, my, sxx, sxy, syy, H, W, tiles_x, tiles_y, center_bias,
-                                     o, fill, cull, rs, cr, cg, cb_, box);
+                                     o, fill, cull, rs, cr, cg, cb_, box, fill ? tl.row0 : 0,
+                                     fill ? tl.row1 : INT_MAX);
     if (fill && listed) emit_tiles(g, box, tl.row0, tl.row1, tiles_x, tl.tile_count, tl.seg, tl.C);
 }
 
