@@ -971,7 +971,10 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
     // (on request only: at 8 x 30 000 Gaussians its two launches take 11 + 13 us against 19.8 us
     // for the aggregated form -- the scan of all boxes by every band is a chain of memory rounds)
     if (by_bands) by_bands = ws->project_agg == 3;
-    if (by_bands && ensure_boxes(ws, (int64_t)frames * N) != GI2D_OK) by_bands = false;
+    if (by_bands && ensure_boxes(ws, (int64_t)frames * N) != GI2D_OK) {
+        (void)hipGetLastError();
+        by_bands = false;
+    }
     // cells: single large frames (buckets of N entries per cell: the cell side grows until the
     // cells fit their limits; a workspace that must not allocate never takes this form)
     CellGrid cells = CellGrid();
@@ -989,8 +992,11 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
                 (int64_t)frames * cells.cells * N * (int64_t)sizeof(int2) <= GI2D_CELLS_MAX_BYTES)
                 break;
         }
-        by_cells = k <= CELL_MAX_LOG2 &&
-                   ensure_cells(ws, (int64_t)frames * cells.cells, N) == GI2D_OK;
+        by_cells = k <= CELL_MAX_LOG2;
+        if (by_cells && ensure_cells(ws, (int64_t)frames * cells.cells, N) != GI2D_OK) {
+            (void)hipGetLastError();  // (no memory for the buckets: another form, not a failure)
+            by_cells = false;
+        }
         cells.log2_side = k;
         cells.row0 = ws->pre_r0;
         cells.row1 = ws->pre_r1;
