@@ -196,6 +196,39 @@ def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
         assert int(got[0][1][-1]) > 2 * 16 * 16384
 
 
+def test_cells_form_on_random_shapes_and_bands():
+    """List filling through cells of tiles against one counter atomic per pair on a seeded
+    sweep of frame sizes (cells cut by the frame's edges), Gaussian counts (less than one
+    workgroup to several), footprints and bands of tile rows that start and end inside cells:
+    same outputs, same lists, same pixels."""
+    import random
+    from gaussianimage_amd import _lib
+    from gaussianimage_amd.pipeline import FramePipeline
+    rnd = random.Random(5)
+    for case in range(14):
+        kind = rnd.choice(["cholesky", "rs"])
+        H, W = rnd.randint(17, 700), rnd.randint(17, 700)
+        N = rnd.choice([1, 37, 900, 1024, 1025, 3000, 6000])
+        fp = rnd.choice([0.5, 1.0, 3.0, 10.0])
+        tiles_y = (H + 15) // 16
+        r0 = rnd.randint(0, tiles_y - 1)
+        rows = None if case % 3 == 0 else (r0, rnd.randint(r0 + 1, tiles_y))
+        inputs = [None if t is None else t.to(DEV).contiguous() for t in _inputs(kind, N, case, fp)]
+        inputs[4] = inputs[4].reshape(-1)
+        got = []
+        for form in (2, 4):
+            pipe = FramePipeline(N, H, W, kind=kind, device=DEV, rows=rows)
+            _lib.check(_lib.lib.gi2d_workspace_set_option(pipe.ws.handle, _lib.OPT_PROJECT_AGG,
+                                                          form), "set_option")
+            for _ in range(3):
+                img = pipe.forward(*inputs).clone()
+            offs, ids = pipe.ws.bins()
+            got.append((img, offs, ids, pipe.xys.clone(), pipe.radii.clone(),
+                        pipe.conics.clone(), pipe.num_tiles_hit.clone()))
+        for x, y in zip(*got):
+            assert torch.equal(x, y), (case, kind, H, W, N, fp, rows)
+
+
 @pytest.mark.parametrize("depth", [1, 2, 3])
 def test_batch_ring_gives_the_bits_of_the_batch_call(depth):
     """Batches in flight on two streams (the projection of one under the rasteriser of the one
