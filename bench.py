@@ -500,6 +500,31 @@ def bench_fused_fit(name, device, steps, concurrent=True):
     return out, fit, gt
 
 
+def bench_full_fit(device, iters=50000):
+    """BASELINE config 4 as a whole: the reference's default fit -- 50 000 iterations
+    (/root/reference/train.py:141-145,287), 50 000 Gaussians, lr 1e-3 with StepLR(20000, 0.5) --
+    of a ~1020x768 synthetic target through the fused fitting step; the host synchronises only at
+    the PSNR read-outs."""
+    from gaussianimage_amd._testing import synth
+    H, W, N, kind, _ = WORKLOADS["div2k50k"]
+    torch.manual_seed(1)
+    fit = make_fitter("div2k50k", device)
+    gt = synth.target_image(H, W).to(device)
+    marks = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, iters + 1):
+        fit.step(gt)
+        if it in (1000, 10000, iters):
+            marks[str(it)] = round(fit.psnr(), 3)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {"workload": f"div2k50k: {W}x{H}, {N} Gaussians, {kind}", "iterations": iters,
+            "wall_s": wall, "ms_per_iteration": wall / iters * 1e3, "psnr_db_at": marks,
+            "overflowed_frames": fit.overflowed_frames,
+            "list_capacity": fit.ws.info()["capacity"]}
+
+
 def secondary(args, device, batch, run, batch_in, B, I_8d, I_held, raster_batch_ms):
     """Per-kernel roofline entries, the training-step half of the metric, and the extras."""
     from gaussianimage_amd.pipeline import FramePipeline
@@ -646,9 +671,47 @@ def secondary(args, device, batch, run, batch_in, B, I_8d, I_held, raster_batch_
             "project", probe_kernel(big.ws, "project", brun), un, Ib, Ibh, uh * uw,
             tiles_of(uh, uw))
         del big, big_in, big_v
+    if args.workload == "kodak30k" and not args.no_concurrent:
+        out["train_step"]["config4_full_fit"] = bench_full_fit(device)
     ex.update(bench_decode(args.workload, device, k))
     out["extras"] = ex
     return out
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n, argv, port):
+    """The command line that runs this script as `n` ranks of one node, one rank per GPU."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+            str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__), *argv]
+
+
+def launch_env(n, visible_gpus, env):
+    """Environment of the ranks.  With fewer GPUs than ranks (a one-GPU development box) the ranks
+    share devices, which RCCL cannot do: the collectives then go through gloo and host memory --
+    a rehearsal of the multi-rank path whose line says so -- unless the caller chose a backend."""
+    env = dict(env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if visible_gpus < n:
+        env.setdefault("GI2D_BENCH_BACKEND", "gloo")
+    return env
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: run the ranks as a child
+    `python -m torch.distributed.run ... bench.py <same arguments>`, pass their output through
+    and return their exit status.  This process makes no GPU call before or after (counting the
+    devices does not initialise HIP)."""
+    import subprocess
+    cmd = launch_command(n, argv, free_port())
+    env = launch_env(n, torch.cuda.device_count(), os.environ)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -683,10 +746,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python bench.py --gpus N`: start the N ranks here (nothing in this process
+        # has touched the GPU yet) and leave with their exit status
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run "
-                             "(--nproc-per-node N)")
+        raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}")
     distributed = world > 1
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -815,7 +880,10 @@ def main():
                                "in one call",
                    "frames_per_step": B, "steps_in_flight": D, "intersections_per_frame": I_8d / B,
                    "list_entries_per_frame": I_held / B, "tiles_per_frame": T,
-                   "parallelism": "1 process/GPU, independent frames per rank"},
+                   "parallelism": "1 process/GPU, independent frames per rank",
+                   **({"collective_backend": dist.get_backend(),
+                       "ranks_share_gpus": world > torch.cuda.device_count()}
+                      if distributed else {})},
         "timed_regions": len(regions), "frames_timed": len(regions) * args.steps * B,
         "region_ms_min_median_max": [min(regions) * 1e3, sorted(regions)[len(regions) // 2] * 1e3,
                                      max(regions) * 1e3],

@@ -5,7 +5,8 @@ config 3: rotation-scale covariance, 768x512, 30 000 Gaussians -- forward AND ba
           gradient element-wise);
 config 4: ~1020x768, 50 000 Gaussians, the fitting loop -- the fused two-launch step against
           its four-launch form (bits), against reference-style training through the drop-in
-          operators (tolerance), and its first loss against the oracle;
+          operators (tolerance), and its first loss against the oracle; and the whole
+          50 000-iteration fit (convergence, no overflow, final loss against the operators);
 config 5: 3840x2160, 200 000 Gaussians split by tile rows over 2 / 4 / 8 ranks -- every band,
           rendered in turn on this one device, is bit-identical to the unsharded frame and the
           per-band gradients sum to the unsharded gradients.
@@ -122,6 +123,50 @@ def test_config4_fused_fit_at_full_size(oracle):
         for s in fused.state[k]:
             assert torch.equal(fused.state[k][s], plain.state[k][s]), (k, s)
     assert fused.loss() < 0.8 * want_loss  # and it is a fit: the loss goes down
+
+
+def test_config4_full_fitting_loop_of_50000_iterations():
+    """BASELINE config 4 as a whole: the reference's default fit (/root/reference/train.py:141-145
+    loop, :287 iterations = 50 000, :295-300 num_points = 50 000, lr = 1e-3; StepLR(20000, 0.5),
+    /root/reference/gaussianimage_cholesky.py:55) of a ~1020x768 target through the fused step.
+    No host synchronisation but at the six PSNR read-outs; the fit must converge, no tile list
+    may overflow on the way, and the final loss is checked against a forward of the final
+    parameters through the drop-in operators."""
+    import time
+    from gaussianimage_amd import ops
+    from gaussianimage_amd.fit import FusedFitter
+    H, W, N, iters = 768, 1020, 50000, 50000
+    gt = synth.target_image(H, W).to(DEV)
+    torch.manual_seed(1)
+    fit = FusedFitter(N, H, W, device=DEV, lr=1e-3, keep_image=False)
+    marks = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, iters + 1):
+        fit.step(gt)
+        if it in (1, 100, 1000, 10000, 25000, iters):
+            marks[it] = fit.psnr()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    print(f"config 4 full fit: {wall:.2f} s, psnr {marks}")
+    assert fit.step_count == iters and abs(fit.lr - 0.25e-3) < 1e-12   # two StepLR halvings
+    assert fit.overflowed_frames == 0
+    vals = [marks[k] for k in sorted(marks)]
+    assert all(b > a for a, b in zip(vals, vals[1:])), marks
+    assert vals[-1] >= 45.0, marks
+    assert wall < 60.0
+    # the last step's loss was taken BEFORE its update; one more forward of the final parameters
+    # through the operators gives a loss no larger than a few percent off it
+    with torch.no_grad():
+        tb = ((W + 15) // 16, (H + 15) // 16, 1)
+        bound = torch.tensor([0.5, 0.0, 0.5], device=DEV)
+        proj = ops.project_gaussians_2d(torch.tanh(fit.params["_xyz"]),
+                                        fit.params["_cholesky"] + bound, H, W, tb)
+        img = ops.rasterize_gaussians_sum(*proj, fit.params["_features_dc"], fit._opacity, H, W,
+                                          16, 16)
+        out = torch.clamp(img, 0, 1).view(-1, H, W, 3).permute(0, 3, 1, 2)
+        mse = float(torch.nn.functional.mse_loss(out, gt).item())
+    assert abs(mse - fit.loss()) <= 0.05 * fit.loss(), (mse, fit.loss())
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

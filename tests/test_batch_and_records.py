@@ -63,6 +63,50 @@ def test_batch_equals_single_frames(kind, F, N, H, W, fp):
     assert batch.ws.info()["frames"] == F and batch.ws.info()["records"]
 
 
+def test_the_benched_batch_against_the_oracle(oracle):
+    """The shape bench.py times -- 24 frames of 768x512 / 30 000 Gaussians in one call, every
+    form left to the library's own choice (LDS-aggregated projection, one wave per tile, packed
+    records, culled lists) -- compared with the oracle directly, not through other entry points:
+    projection outputs bit for bit, images within 1e-5 (pixels on the alpha cut set aside), and,
+    with the support culling switched off, the tile lists bit for bit."""
+    import bench
+    from gaussianimage_amd.pipeline import FrameBatch
+    F, (H, W, N, kind, fp) = 24, bench.WORKLOADS["kodak30k"]
+    stack = bench.make_batch_inputs("kodak30k", DEV, F, seed=1)
+    batch = FrameBatch(F, N, H, W, kind=kind, device=DEV)
+    run = batch.bind(*stack)
+    for _ in range(3):
+        run()
+    imgs = batch.images.clone()
+    T = batch.tiles_x * batch.tiles_y
+    offs, ids = batch.ws.bins()
+    batch.ws.set_cull(False)
+    run()
+    assert torch.equal(batch.images, imgs)       # (culling drops only pairs that contribute nothing)
+    full_offs, full_ids = batch.ws.bins()
+    batch.ws.set_cull(True)
+    assert int(offs[-1]) < int(full_offs[-1])
+    for f in (0, 13, 23):
+        means, L, col, op = (stack[0][f].cpu().numpy(), stack[1][f].cpu().numpy(),
+                             stack[3][f].cpu().numpy(), stack[4][f].cpu().numpy().reshape(N, 1))
+        r_xys, r_depths, r_radii, r_conics, r_nth = oracle.project_cholesky_fwd(means, L, H, W)
+        assert np.array_equal(batch.xys[f].cpu().numpy(), r_xys), f
+        assert np.array_equal(batch.radii[f].cpu().numpy(), r_radii), f
+        assert np.array_equal(batch.conics[f].cpu().numpy(), r_conics), f
+        assert np.array_equal(batch.num_tiles_hit[f].cpu().numpy(), r_nth), f
+        r_offs, r_ids = oracle.bin_tiles(r_xys, r_radii, H, W)
+        b_offs = full_offs[f * T:(f + 1) * T + 1].numpy()
+        assert np.array_equal(b_offs - b_offs[0], r_offs), f
+        assert np.array_equal(full_ids[int(b_offs[0]):int(b_offs[-1])].numpy(), r_ids), f
+        ref, margin = oracle.rasterize_sum_fwd(r_xys, r_conics, col, op, H, W, r_offs, r_ids,
+                                               want_margin=True)
+        ok = margin > 1e-4
+        assert ok.mean() > 0.995
+        err = np.abs(imgs[f].cpu().numpy() - ref)
+        assert err[ok].max() <= 1e-5, (f, err[ok].max())
+        assert err.max() <= 3.0 / 255 * max(1.0, float(col.max()))
+
+
 def test_batch_argument_errors():
     from gaussianimage_amd import _lib
     from gaussianimage_amd.pipeline import FrameBatch

@@ -33,6 +33,64 @@ def test_cpu_baseline_leg_reports_what_it_sampled():
     assert r["cores"] >= 1 and "kodak5k" in r["sample"]
 
 
+def test_gpus_without_a_launcher_starts_the_ranks_itself(monkeypatch):
+    """`python bench.py --gpus N` typed without torch.distributed.run: the script runs its ranks
+    as a child launcher process with the same arguments and hands back their exit status."""
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "20", "--warmup", "5"], 29555)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29555"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    # enough GPUs: RCCL (the default backend) is left alone; fewer GPUs than ranks: a gloo rehearsal
+    assert "GI2D_BENCH_BACKEND" not in bench.launch_env(4, 8, {})
+    assert bench.launch_env(4, 1, {})["GI2D_BENCH_BACKEND"] == "gloo"
+    assert bench.launch_env(4, 1, {"GI2D_BENCH_BACKEND": "nccl"})["GI2D_BENCH_BACKEND"] == "nccl"
+    assert bench.launch_env(2, 2, {})["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    assert seen["cmd"][-4:] == ["--gpus", "2", "--steps", "3"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and \
+        seen["cmd"][seen["cmd"].index("--nproc-per-node") + 1] == "2"
+
+
+@pytest.mark.gpu
+def test_gpus_2_typed_without_a_launcher_reaches_the_rank_code():
+    """On a box with one GPU the two ranks share it and exchange through gloo: the line is a
+    rehearsal of the multi-rank path and says so."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["GI2D_SHARD_TIMEOUT_S"] = "200"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+                          "10", "--warmup", "2"], capture_output=True, text=True, timeout=420,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "tile_row_sharded" in d and "error" not in d["tile_row_sharded"], d["tile_row_sharded"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert d["config"]["collective_backend"] == "gloo" and d["config"]["ranks_share_gpus"]
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "24", "--warmup",
