@@ -78,7 +78,7 @@ def test_the_benched_batch_against_the_oracle(oracle):
     for _ in range(3):
         run()
     imgs = batch.images.clone()
-    T = batch.tiles_x * batch.tiles_y
+    T = bench.tiles_of(H, W)
     offs, ids = batch.ws.bins()
     batch.ws.set_cull(False)
     run()
