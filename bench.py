@@ -110,6 +110,16 @@ def algorithmic_bytes(kernel, N, I, P, T):
     }[kernel]
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def time_cpu_oracle(name, budget_s=12.0):
     """CPU baseline: this repository's C restatement (oracle) of the same forward path."""
     from gaussianimage_amd._testing import synth
@@ -145,8 +155,11 @@ def time_cpu_oracle(name, budget_s=12.0):
 
     n, el = run(budget_s, 1000)
     out = {"value": n / el, "unit": "frames/s", "cores": threads, "kind": "port",
-           "sample": f"{n} forward frames of {name} (project+bin+rasterize) in {el:.1f} s; "
-                     "rasterize loop OpenMP-parallel over tiles, projection and binning serial"}
+           "host_cores": os.cpu_count(), "host_cpu": host_cpu_model(),
+           "sample": f"{n} forward frames of {name} (project+bin+rasterize) in {el:.1f} s on "
+                     f"{threads} OpenMP threads (the box's share of a {os.cpu_count()}-CPU host): "
+                     "projection parallel over Gaussians, binning over bands of tile rows, "
+                     "rasterisation over tiles"}
     try:  # the same on one core (a few frames), as a second reference point
         import ctypes
         gomp = ctypes.CDLL("libgomp.so.1")

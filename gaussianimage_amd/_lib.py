@@ -30,6 +30,7 @@ OPT_DROP_PENDING = 3
 OPT_BWD_SERIAL = 4
 OPT_RECORDS = 5
 OPT_PROJECT_AGG = 6
+OPT_FAIL_SIDE_ALLOCS = 7
 PROBE = {"project": 1, "raster_fwd": 2, "raster_bwd": 3, "gather": 4, "fit_raster": 5,
          "fit_tail": 6}
 

@@ -45,6 +45,7 @@ struct gi2d_workspace {
     // list filling of a projection: 0 auto, 1 aggregated in LDS per workgroup, 2 direct (one
     // counter atomic per pair), 3 by bands of tile rows (no counter atomics)
     int project_agg = 0;
+    bool fail_side_allocs = false;  // testing aid: bucket / box allocations report out of memory
     int *d_box = nullptr;            // packed tile boxes of the band-wise list filling
     int64_t box_cap = 0;
     // list filling through cells (large frames): per-cell counters and buckets

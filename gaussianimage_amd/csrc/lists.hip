@@ -201,11 +201,12 @@ int ensure_cells(gi2d_workspace *ws, int64_t cells, int N)
         ws->cell_count_cap = cells;
     }
     const int64_t want = cells * N;
-    if (ws->cell_bucket_cap >= want) return GI2D_OK;
+    if (ws->cell_bucket_cap >= want && !ws->fail_side_allocs) return GI2D_OK;
     HIP_TRY(hipDeviceSynchronize());
     if (ws->d_cell_bucket) (void)hipFree(ws->d_cell_bucket);
     ws->d_cell_bucket = nullptr;
     ws->cell_bucket_cap = 0;
+    if (ws->fail_side_allocs) return (int)hipErrorOutOfMemory;  // (testing aid: as if no memory)
     HIP_TRY(hipMalloc(&ws->d_cell_bucket, 2 * sizeof(int) * (size_t)want));
     ws->cell_bucket_cap = want;
     return GI2D_OK;
@@ -214,11 +215,12 @@ int ensure_cells(gi2d_workspace *ws, int64_t cells, int N)
 // One packed tile box per Gaussian for `count` Gaussians; the device is current.
 int ensure_boxes(gi2d_workspace *ws, int64_t count)
 {
-    if (ws->box_cap >= count) return GI2D_OK;
+    if (ws->box_cap >= count && !ws->fail_side_allocs) return GI2D_OK;
     HIP_TRY(hipDeviceSynchronize());
     if (ws->d_box) (void)hipFree(ws->d_box);
     ws->d_box = nullptr;
     ws->box_cap = 0;
+    if (ws->fail_side_allocs) return (int)hipErrorOutOfMemory;  // (testing aid: as if no memory)
     HIP_TRY(hipMalloc(&ws->d_box, sizeof(int) * (size_t)count));
     ws->box_cap = count;
     return GI2D_OK;
@@ -420,6 +422,9 @@ int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value)
         case GI2D_OPT_BWD_SERIAL:
             if (value < 0) return GI2D_E_INVALID;
             ws->bwd_serial = value;
+            return GI2D_OK;
+        case GI2D_OPT_FAIL_SIDE_ALLOCS:
+            ws->fail_side_allocs = value != 0;
             return GI2D_OK;
         default: return GI2D_E_INVALID;
     }

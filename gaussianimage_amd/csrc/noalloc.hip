@@ -30,6 +30,7 @@ struct NoAllocDevice {
 };
 NoAllocDevice g_dev[NA_MAX_DEVICES];
 std::mutex g_setup_lock;
+std::mutex g_call_lock;  // serialises the host side of gi2d_render_frame_noalloc
 }  // namespace
 
 // Once per device, with that device current: the address of its copy of the array.
@@ -81,6 +82,11 @@ int gi2d_render_frame_noalloc(const gi2d_frame_args *a, int per_tile_capacity)
     NoAllocDevice *d = nullptr;
     int rc = noalloc_setup(dev, &d);
     if (rc != GI2D_OK) return rc;
+    // One call at a time per process edits the bookkeeping and enqueues the launches (host work
+    // only, a few microseconds): two host threads cannot interleave their edits of one device's
+    // struct.  The lock says nothing about the GPU: launches of two calls that OVERLAP on one
+    // device still share the array, and that remains the caller's to avoid.
+    std::lock_guard<std::mutex> hold(g_call_lock);
     // The bookkeeping of a workspace whose lists already have this frame's shape and capacity:
     // nothing is learned synchronously, nothing grows, and the counters -- which may hold what
     // an interrupted earlier call left -- are cleared by a fill kernel before the projection.

@@ -67,6 +67,7 @@ struct WsState {
     int device = 0;
     BinKey key, counted_key;
     at::Tensor keep_xys, keep_radii;  // strong references: their storage must not be recycled
+    at::Tensor counted_xys, counted_radii;  // the same for the tensors behind counted_key
     int64_t late_overflows = 0;
     bool strict = false, sync_binning = false;
 
@@ -81,11 +82,22 @@ struct WsState {
     void invalidate(bool counted)
     {
         key.valid = false;
-        if (counted) counted_key.valid = false;
+        if (counted) drop_counted();
     }
+    void drop_counted()
+    {
+        counted_key.valid = false;
+        counted_xys = at::Tensor();
+        counted_radii = at::Tensor();
+    }
+    // The projection that produced xys / radii also filled the lists.  Detached aliases hold the
+    // storage (and no autograd graph): while the key is valid the allocator cannot hand the same
+    // addresses, with a fresh version counter, to unrelated tensors.
     void set_counted(const at::Tensor &xys, const at::Tensor &radii, int H, int W)
     {
         counted_key = make_key(xys, radii, H, W);
+        counted_xys = xys.detach();
+        counted_radii = radii.detach();
     }
 };
 
@@ -149,7 +161,7 @@ void bin(WsState &ws, const at::Tensor &xys, const at::Tensor &radii, int H, int
     const int tiles_x = (W + GI2D_BLOCK - 1) / GI2D_BLOCK, tiles_y = (H + GI2D_BLOCK - 1) / GI2D_BLOCK;
     if (ws.sync_binning) flags |= GI2D_BIN_SYNC;
     if (ws.counted_key == key) flags |= GI2D_BIN_COUNTED;
-    ws.counted_key.valid = false;
+    ws.drop_counted();
     ws.key.valid = false;
     int rc = gi2d_bin_tiles(ws.handle, xys.numel() ? xys.data_ptr<float>() : nullptr,
                             radii.numel() ? radii.data_ptr<int>() : nullptr, (int)xys.size(0),
@@ -159,14 +171,21 @@ void bin(WsState &ws, const at::Tensor &xys, const at::Tensor &radii, int H, int
         // the lists have been enlarged since, and the binning asked for now is complete
         ws.late_overflows += 1;
         if (ws.strict) raise_status(rc, "gi2d_bin_tiles", have_gil);
-        if (ws.late_overflows == 1) {
-            // a Python warning like the ctypes binding's (the backward runs on an autograd
-            // thread that does not hold the interpreter lock)
+        {
+            // a Python warning like the ctypes binding's, on EVERY occurrence (the text differs
+            // from one to the next, so the once-per-location filter does not hide the later
+            // ones; the backward runs on an autograd thread without the interpreter lock)
+            int64_t info[10] = {0};
+            gi2d_workspace_info(ws.handle, info);
+            std::ostringstream msg;
+            msg << "gaussianimage_amd: an earlier frame overflowed a tile list -- its overflowed "
+                   "tiles were NaN-filled, so a loss or PSNR computed from that image is NaN "
+                   "(occurrence " << ws.late_overflows << " on this workspace, lists at generation "
+                << info[2] << ", capacity now " << info[0] << " per tile). The lists have been "
+                   "enlarged; this call is complete. Set GI2D_SYNC=1 (or strict on the workspace "
+                   "to raise instead) to size the lists synchronously in every call.";
             py::gil_scoped_acquire gil;
-            if (PyErr_WarnEx(PyExc_RuntimeWarning,
-                             "gaussianimage_amd: an earlier frame overflowed a tile list (its "
-                             "overflowed tiles were NaN-filled); the lists have been enlarged. Set "
-                             "GI2D_SYNC=1 to size the lists synchronously in every call.", 2) < 0)
+            if (PyErr_WarnEx(PyExc_RuntimeWarning, msg.str().c_str(), 2) < 0)
                 throw py::error_already_set();
         }
         rc = GI2D_OK;

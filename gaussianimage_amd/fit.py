@@ -207,10 +207,15 @@ class BatchFitter:
     iteration of ``FusedFitter`` over all of them in one call (three launches from four images
     on).  Parameters, optimizer
     state and outputs are ``[frames, N, ...]`` tensors (``params["_xyz"][f]`` is image f's
-    ``_xyz``); targets are one contiguous ``[frames, 3, H, W]`` tensor.  Image f follows, bit for
-    bit, the trajectory ``FusedFitter`` gives it alone.  For the reference's loop over the images
-    of a dataset (/root/reference/train.py:366-372), where one 768x512 fit leaves most of the
-    chip idle.
+    ``_xyz``); targets are one contiguous ``[frames, 3, H, W]`` tensor.  Image f follows the
+    trajectory ``FusedFitter`` gives it alone -- bit for bit when both run the same workgroup
+    shape (``Workspace.set_raster_ppl``).  Left to themselves they may not: a batch of four or
+    more images projects through the LDS-aggregated kernel and, from 20 480 tiles per launch,
+    rasterises with one wave per tile where a single 768x512 image takes four; the backward then
+    adds a Gaussian's per-pixel terms in another order, and the last-bit gradient differences
+    grow to ~6e-4 of a parameter within a few Adan steps.  For the reference's loop over the
+    images of a dataset (/root/reference/train.py:366-372), where one 768x512 fit leaves most of
+    the chip idle.
     """
 
     def __init__(self, frames, num_points, H, W, kind="cholesky", device="cuda:0", lr=1e-3,

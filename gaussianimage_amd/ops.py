@@ -121,6 +121,15 @@ def _f32c(t):
     return t.to(torch.float32).contiguous()
 
 
+def _late_overflow_text(count, info):
+    return ("gaussianimage_amd: an earlier frame overflowed a tile list -- its overflowed tiles "
+            "were NaN-filled, so a loss or PSNR computed from that image is NaN (occurrence %d on "
+            "this workspace, lists at generation %d, capacity now %d per tile). The lists have "
+            "been enlarged; this call is complete. Set GI2D_SYNC=1 (or Workspace.strict = True to "
+            "raise instead) to size the lists synchronously in every call."
+            % (count, info["generation"], info["capacity"]))
+
+
 class Workspace:
     """Owns the device-side tile lists of one device (``gi2d_workspace``)."""
 
@@ -132,7 +141,8 @@ class Workspace:
         self.handle = h
         self.key = None       # identity of the tensors the current lists were built from
         self.keep = None      # strong references: keeps their storage from being recycled
-        self.counted_key = None
+        self._counted_key = None
+        self._counted_keep = None   # the storage behind counted_key, held for the same reason
         self.rows = (0, 2 ** 31 - 1)
         self.sync_binning = os.environ.get("GI2D_SYNC", "0") == "1"
         self.late_overflows = 0   # GI2D_E_PREV_OVERFLOW reports swallowed by bin()
@@ -145,6 +155,24 @@ class Workspace:
                 lib.gi2d_workspace_destroy(h)
             except Exception:
                 pass
+
+    @property
+    def counted_key(self):
+        """Identity of the projection outputs whose lists the projection itself prefilled."""
+        return self._counted_key
+
+    @counted_key.setter
+    def counted_key(self, key):
+        self._counted_key = key
+        if key is None:
+            self._counted_keep = None
+
+    def set_counted(self, xys, radii, H, W):
+        """The projection that produced ``xys`` / ``radii`` also filled the lists: remember
+        which tensors, and hold their storage (a detached alias, no autograd graph) so that the
+        allocator cannot hand the same addresses to other tensors while the key is valid."""
+        self._counted_key = self._key(xys, radii, H, W)
+        self._counted_keep = (xys.detach(), radii.detach())
 
     def info(self):
         arr = (ctypes.c_int64 * 10)()
@@ -203,11 +231,10 @@ class Workspace:
             self.late_overflows += 1
             if self.strict:
                 raise _lib.Gi2dError(rc, "gi2d_bin_tiles")
-            if self.late_overflows == 1:
-                warnings.warn("gaussianimage_amd: an earlier frame overflowed a tile list (its "
-                              "overflowed tiles were NaN-filled); the lists have been enlarged. "
-                              "Set GI2D_SYNC=1 to size the lists synchronously in every call.",
-                              RuntimeWarning, stacklevel=3)
+            # every occurrence is reported (the text differs from one to the next, so the
+            # warning filter's once-per-location rule does not hide the later ones)
+            warnings.warn(_late_overflow_text(self.late_overflows, self.info()),
+                          RuntimeWarning, stacklevel=3)
             rc = _lib.GI2D_OK
         check(rc, "gi2d_bin_tiles")
         self.key = key
@@ -361,7 +388,7 @@ class _ProjectGaussians2d(torch.autograd.Function):
                                             ctypes.byref(_CONV), _ptr(xys), _ptr(depths),
                                             _ptr(radii), _ptr(conics), _ptr(nth), ws.handle,
                                             _stream(m.device)), "gi2d_project_cholesky_fwd")
-        ws.counted_key = Workspace._key(xys, radii, img_height, img_width)
+        ws.set_counted(xys, radii, img_height, img_width)
         ctx.save_for_backward(m, L)
         ctx.hw = (img_height, img_width)
         ctx.mark_non_differentiable(depths, radii, nth)
@@ -396,7 +423,7 @@ class _ProjectGaussians2dScaleRot(torch.autograd.Function):
                                       ctypes.byref(_CONV), _ptr(xys), _ptr(depths), _ptr(radii),
                                       _ptr(conics), _ptr(nth), ws.handle, _stream(m.device)),
               "gi2d_project_rs_fwd")
-        ws.counted_key = Workspace._key(xys, radii, img_height, img_width)
+        ws.set_counted(xys, radii, img_height, img_width)
         ctx.save_for_backward(m, s, r)
         ctx.hw = (img_height, img_width)
         ctx.mark_non_differentiable(depths, radii, nth)

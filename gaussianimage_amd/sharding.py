@@ -256,6 +256,13 @@ class ShardedFitter:
         f._check_target(gt_image)
         if f.ws.rows != self.rows:
             f.ws.set_rows(*self.rows)
+        # The two kernels run on the stream the fitter was bound to, the all-reduce on torch's
+        # current stream: they are ordered only when these are the same stream.
+        from .ops import _stream
+        if _stream(f.device) != f._stream:
+            raise RuntimeError("ShardedFitter.step must be called on the stream the fitter was "
+                               "created on (its kernels and the all-reduce are ordered by "
+                               "running on one stream)")
         lr = f.lr
         rc = lib.gi2d_fit_raster(*self._raster_args, _ptr(gt_image), *self._raster_tail, f._stream)
         _lib.check(f._late_overflow(rc), "gi2d_fit_raster")

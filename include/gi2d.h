@@ -76,7 +76,10 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
 #define GI2D_OPT_CULL 1
 /* GI2D_OPT_RASTER_PPL: pixels per lane of the forward rasteriser: 1, 2 or 4
  * (workgroups of 4, 2 or 1 waves per tile), 0 (default) = chosen from the tile
- * count.  A tuning knob: every setting gives the same bits. */
+ * count.  A tuning knob: every setting gives the same FORWARD bits (images, losses).  The
+ * backward and fused fitting kernels follow the same setting, and their one-wave form adds a
+ * Gaussian's per-pixel terms in another order than the four-wave form: gradients agree to
+ * rounding, not to the bit, across settings. */
 #define GI2D_OPT_RASTER_PPL 2
 /* GI2D_OPT_DROP_PENDING (any value): forget the projection a chained fitting
  * step prepared for the next iteration (see gi2d_fit_backward_step_chain); the
@@ -107,6 +110,11 @@ int gi2d_workspace_reserve(gi2d_workspace *ws, int64_t per_tile_capacity, int ma
  * the stamps of the backward's partial sums derive (1 .. INT_MAX, then the slots are cleared
  * and the stamps start over), so that a test can cross the wrap. */
 #define GI2D_OPT_BWD_SERIAL 4
+/* GI2D_OPT_FAIL_SIDE_ALLOCS (testing aid): while non-zero, the allocations of the list-filling
+ * forms' side buffers (cell buckets, packed tile boxes) report "out of memory" without calling
+ * hipMalloc; the projection must then fall back to a form that needs none and give the same
+ * lists. */
+#define GI2D_OPT_FAIL_SIDE_ALLOCS 7
 int gi2d_workspace_set_option(gi2d_workspace *ws, int option, int value);
 /* Instrumentation: from now on the library records begin_event right before and end_event right
  * after every launch of one kind of kernel on this workspace (hipEvent_t, created by the caller
@@ -268,8 +276,12 @@ int gi2d_render_batch(gi2d_workspace *ws, int kind, int frames, const float *mea
  * array gives this frame, at most 4096.  There is no growth: a tile whose list is longer has
  * its pixels set to NaN (never silently wrong), as in the asynchronous workspace path.
  * Results are bit-identical to gi2d_render_frame's.  Every call on a GPU shares that GPU's
- * array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream
- * are ordered and each clears what it needs cleared. */
+ * array: calls whose GPU work overlaps on one GPU (two streams, two threads) race; calls on one
+ * stream are ordered and each clears what it needs cleared.  The host side is serialised by a
+ * lock inside the library (two host threads may call it; their launches must still not overlap
+ * on one device).  The FIRST call on a device looks up the array's address
+ * (hipGetSymbolAddress) and must be made outside graph capture; a captured call bakes that
+ * call's list generation and capacity into the kernel arguments, which is what a replay needs. */
 #define GI2D_NOALLOC_MAX_TILES 34816
 #define GI2D_NOALLOC_MAX_LIST_INTS 2097152
 int gi2d_render_frame_noalloc(const gi2d_frame_args *args, int per_tile_capacity);

@@ -26,6 +26,7 @@
  * (radii, tile boxes, tile lists) can be matched bit for bit by the GPU code.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -131,6 +132,7 @@ void oracle_project_cholesky_fwd(int N, const float *means, const float *L, int 
                                  int tiles_x, int tiles_y, const gi2d_conv *cv, float *xys,
                                  float *depths, int *radii, float *conics, int *num_tiles_hit)
 {
+#pragma omp parallel for schedule(static)
     for (int g = 0; g < N; ++g) {
         float l11 = L[3 * g], l21 = L[3 * g + 1], l22 = L[3 * g + 2];
         float sxx = l11 * l11;
@@ -147,6 +149,7 @@ void oracle_project_rs_fwd(int N, const float *means, const float *scales, const
                            int W, int tiles_x, int tiles_y, const gi2d_conv *cv, float *xys,
                            float *depths, int *radii, float *conics, int *num_tiles_hit)
 {
+#pragma omp parallel for schedule(static)
     for (int g = 0; g < N; ++g) {
         float c, s;
         gi2d_sincos_f32(rot[g], &s, &c);
@@ -169,12 +172,19 @@ int64_t oracle_bin_tiles(int N, const float *xys, const int *radii, int tiles_x,
 {
     int T = tiles_x * tiles_y;
     int *cnt = (int *)calloc((size_t)T + 1, sizeof(int));
-    for (int g = 0; g < N; ++g) {
-        if (radii[g] <= 0) continue;
-        int box[4];
-        oracle_tile_box(xys[2 * g], xys[2 * g + 1], (float)radii[g], tiles_x, tiles_y, box);
-        for (int ty = box[2]; ty < box[3]; ++ty)
-            for (int tx = box[0]; tx < box[1]; ++tx) cnt[ty * tiles_x + tx]++;
+    /* Threads own disjoint bands of tile rows and each walks all Gaussians in ascending order:
+     * the lists are those of the serial loop, whatever the thread count. */
+#pragma omp parallel
+    {
+        int nt = omp_get_num_threads(), me = omp_get_thread_num();
+        int r0 = (int)((int64_t)tiles_y * me / nt), r1 = (int)((int64_t)tiles_y * (me + 1) / nt);
+        for (int g = 0; g < N && r0 < r1; ++g) {
+            if (radii[g] <= 0) continue;
+            int box[4];
+            oracle_tile_box(xys[2 * g], xys[2 * g + 1], (float)radii[g], tiles_x, tiles_y, box);
+            for (int ty = imax(box[2], r0); ty < imin(box[3], r1); ++ty)
+                for (int tx = box[0]; tx < box[1]; ++tx) cnt[ty * tiles_x + tx]++;
+        }
     }
     int64_t total = 0;
     for (int t = 0; t < T; ++t) {
@@ -184,15 +194,21 @@ int64_t oracle_bin_tiles(int N, const float *xys, const int *radii, int tiles_x,
     tile_offsets[T] = (int)total;
     if (ids && total <= ids_capacity) {
         memset(cnt, 0, sizeof(int) * (size_t)T);
-        for (int g = 0; g < N; ++g) {
-            if (radii[g] <= 0) continue;
-            int box[4];
-            oracle_tile_box(xys[2 * g], xys[2 * g + 1], (float)radii[g], tiles_x, tiles_y, box);
-            for (int ty = box[2]; ty < box[3]; ++ty)
-                for (int tx = box[0]; tx < box[1]; ++tx) {
-                    int t = ty * tiles_x + tx;
-                    ids[tile_offsets[t] + cnt[t]++] = g;
-                }
+#pragma omp parallel
+        {
+            int nt = omp_get_num_threads(), me = omp_get_thread_num();
+            int r0 = (int)((int64_t)tiles_y * me / nt);
+            int r1 = (int)((int64_t)tiles_y * (me + 1) / nt);
+            for (int g = 0; g < N && r0 < r1; ++g) {
+                if (radii[g] <= 0) continue;
+                int box[4];
+                oracle_tile_box(xys[2 * g], xys[2 * g + 1], (float)radii[g], tiles_x, tiles_y, box);
+                for (int ty = imax(box[2], r0); ty < imin(box[3], r1); ++ty)
+                    for (int tx = box[0]; tx < box[1]; ++tx) {
+                        int t = ty * tiles_x + tx;
+                        ids[tile_offsets[t] + cnt[t]++] = g;
+                    }
+            }
         }
     }
     free(cnt);
@@ -352,6 +368,7 @@ void oracle_project_cholesky_bwd(int N, const float *means, const float *L, int 
                                  float *v_L)
 {
     (void)means;
+#pragma omp parallel for schedule(static)
     for (int g = 0; g < N; ++g) {
         float l11 = L[3 * g], l21 = L[3 * g + 1], l22 = L[3 * g + 2];
         v_means[2 * g] = v_means[2 * g + 1] = 0.0f;

@@ -240,6 +240,40 @@ def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
         assert int(got[0][1][-1]) > 2 * 16 * 16384
 
 
+@pytest.mark.parametrize("form", [4, 3])
+def test_a_failed_side_buffer_allocation_falls_back_to_another_form(form):
+    """The cells form needs buckets, the bands form a box per Gaussian.  When that allocation
+    fails the projection takes a form that needs none -- no error, no sticky HIP error, the same
+    outputs, lists and images -- and takes the requested form again once memory is there."""
+    from gaussianimage_amd import _lib
+    from gaussianimage_amd.pipeline import FrameBatch
+    kind, F, N, H, W = "cholesky", 2, 9000, 256, 320
+    per = [_inputs(kind, N, 40 + f, 1.5) for f in range(F)]
+    stack = [None if per[0][k] is None else
+             torch.stack([p[k].reshape(N, -1) for p in per]).to(DEV).contiguous() for k in range(5)]
+    stack[4] = stack[4].reshape(F, N)
+
+    def state(b):
+        offs, ids = b.ws.bins()
+        return (b.images.clone(), offs, ids, b.xys.clone(), b.radii.clone(), b.num_tiles_hit.clone())
+
+    ref = FrameBatch(F, N, H, W, kind=kind, device=DEV)
+    _lib.check(_lib.lib.gi2d_workspace_set_option(ref.ws.handle, _lib.OPT_PROJECT_AGG, 2), "opt")
+    for _ in range(3):
+        ref.forward(*stack)
+    want = state(ref)
+    b = FrameBatch(F, N, H, W, kind=kind, device=DEV)
+    _lib.check(_lib.lib.gi2d_workspace_set_option(b.ws.handle, _lib.OPT_PROJECT_AGG, form), "opt")
+    for failing in (1, 0, 1, 0):
+        _lib.check(_lib.lib.gi2d_workspace_set_option(b.ws.handle, _lib.OPT_FAIL_SIDE_ALLOCS,
+                                                      failing), "opt")
+        for _ in range(3):
+            b.forward(*stack)
+        for x, y in zip(state(b), want):
+            assert torch.equal(x, y), failing
+        torch.cuda.synchronize()     # (raises if a HIP error was left behind)
+
+
 def test_cells_form_on_random_shapes_and_bands():
     """List filling through cells of tiles against one counter atomic per pair on a seeded
     sweep of frame sizes (cells cut by the frame's edges), Gaussian counts (less than one

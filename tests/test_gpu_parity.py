@@ -1204,8 +1204,9 @@ def test_two_streams_through_the_operators_do_not_share_lists(ops, oracle):
 
 
 def test_late_overflow_report_does_not_stop_the_operators(ops, oracle):
-    """The operators swallow the report of an EARLIER frame's overflow (count it, warn once);
-    strict=True brings the exception back."""
+    """The operators swallow the report of an EARLIER frame's overflow: they count it and warn
+    on every occurrence (with the occurrence number and the lists' generation), and the image of
+    the call that carries the report is complete; strict=True brings the exception back."""
     import warnings
     from gaussianimage_amd import _lib
     H, W, N = 64, 64, 1500
@@ -1238,7 +1239,46 @@ def test_late_overflow_report_does_not_stop_the_operators(ops, oracle):
                                                   W, 16, 16)
                 torch.cuda.synchronize()
         assert 1 <= ws.late_overflows - before <= 2 and torch.isfinite(img).all()
-        assert any("overflowed a tile list" in str(w.message) for w in caught)
+        told = [str(w.message) for w in caught if "overflowed a tile list" in str(w.message)]
+        assert len(told) == ws.late_overflows - before     # one warning per occurrence
+        assert all("generation" in t and "NaN" in t for t in told)
+
+
+@pytest.mark.parametrize("compiled", [True, False])
+def test_recycled_projection_outputs_are_not_taken_for_the_projected_ones(ops, oracle, compiled):
+    """The projection prefills the tile lists for ITS outputs.  If those outputs die unrasterised
+    and the allocator hands their addresses to unrelated xys / radii tensors of the same shape,
+    the rasteriser must bin the new tensors, not reuse the prefilled lists."""
+    if compiled and not ops.compiled_binding():
+        pytest.skip("compiled binding not loaded")
+    prev = ops.use_compiled(compiled)
+    try:
+        H, W, N = 64, 80, 700
+        tb = oracle.tile_bounds(H, W)
+        means, L, col, op = synth.cholesky_inputs(N, seed=21)
+        other_means, other_L, _, _ = synth.cholesky_inputs(N, seed=22, footprint=2.0)
+        want = oracle.project_cholesky_fwd(other_means.numpy(), other_L.numpy(), H, W)
+        col_d, op_d = col.to(DEV), op.to(DEV)
+        for _ in range(3):
+            proj = ops.project_gaussians_2d(means.to(DEV), L.to(DEV), H, W, tb)
+            torch.cuda.synchronize()
+            del proj                      # never rasterised; its blocks go back to the allocator
+            xys = torch.from_numpy(want[0]).to(DEV)          # fresh tensors, version 0
+            depths = torch.zeros(N, device=DEV)
+            radii = torch.from_numpy(want[2]).to(DEV)
+            conics = torch.from_numpy(want[3]).to(DEV)
+            nth = torch.from_numpy(want[4]).to(DEV)
+            img = ops.rasterize_gaussians_sum(xys, depths, radii, conics, nth, col_d, op_d, H, W,
+                                              16, 16)
+            offs, ids = ops.get_workspace(DEV).bins()
+            r_offs, r_ids = oracle.bin_tiles(want[0], want[2], H, W)
+            assert np.array_equal(offs.numpy(), r_offs) and np.array_equal(ids.numpy(), r_ids)
+            ref, margin = oracle.rasterize_sum_fwd(want[0], want[3], col.numpy(), op.numpy(), H, W,
+                                                   r_offs, r_ids, want_margin=True)
+            assert np.abs(_np(img) - ref)[margin > 1e-4].max() <= IMG_ATOL
+            del xys, depths, radii, conics, nth, img
+    finally:
+        ops.use_compiled(prev)
 
 
 @pytest.mark.gpu
