@@ -415,6 +415,19 @@ int main()
                         k_pairloop_counted<4, 4><<<b, 256>>>(d_out, rounds, d_rec, 1.f / 255.f, ENTRIES, d_st);
                     }, d_st, cus))
             return 1;
+    // short lists, as a 768x512 / 30 000 frame has them: 16 evaluations per quadrant loop
+    for (int w : ws)
+        if (time_it("pairloop4_bitscan_n16", w, 14.0 * 4 * 16 * rounds * 4,
+                    [&](int b) {
+                        k_pairloop<4><<<b, 256>>>(d_out, rounds * 4, d_rec, 1.f / 255.f, 0xffffull, d_st);
+                    }, d_st, cus))
+            return 1;
+    for (int w : ws)
+        if (time_it("pairloop4_counted_u2_n16", w, 13.0 * 4 * 16 * rounds * 4,
+                    [&](int b) {
+                        k_pairloop_counted<4, 2><<<b, 256>>>(d_out, rounds * 4, d_rec, 1.f / 255.f, 16, d_st);
+                    }, d_st, cus))
+            return 1;
     // records of 1M Gaussians (48 MB: beyond the scalar caches, inside L2 + Infinity Cache), ids
     // at random as in a tile's list
     const int NG = 1 << 20;
