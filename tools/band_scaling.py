@@ -1,5 +1,11 @@
-"""Predicts tile-row scaling on one GPU: times the band a rank would own when the 3840x2160 /
-200k frame is split over R ranks (rank 0's and a middle rank's band), forward only."""
+"""Predicts tile-row scaling on one GPU: times the band a rank would own when a frame is split
+over R ranks (rank 0's and a middle rank's band), forward and forward + backward, and prints the
+speed-up over the whole frame on this GPU.
+
+    python tools/band_scaling.py [--height 2160 --width 3840 --points 200000]
+"""
+import argparse
+import json
 import os
 import sys
 import time
@@ -7,30 +13,77 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from bench import WORKLOADS, make_inputs  # noqa: E402
+from gaussianimage_amd._testing import synth  # noqa: E402
 from gaussianimage_amd.pipeline import FramePipeline  # noqa: E402
-from gaussianimage_amd.sharding import band_plan  # noqa: E402
+from gaussianimage_amd.sharding import ShardedFitter, band_pixels, band_plan  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--points", type=int, default=200000)
+ap.add_argument("--reps", type=int, default=200)
+ap.add_argument("--fit-ppl", type=int, default=0, help="workgroup shape of the fused fit (0 = library)")
+args = ap.parse_args()
 dev = torch.device("cuda:0")
-H, W, N, kind, _ = WORKLOADS["uhd200k"]
-inputs = make_inputs("uhd200k", dev, seed=1)
+H, W, N = args.height, args.width, args.points
+means, L, col, op = synth.cholesky_inputs(N, seed=1)
+inputs = (means.to(dev), L.to(dev), None, col.to(dev), op.reshape(-1).to(dev))
+v_img = torch.randn(H, W, 3, device=dev)
+gt = synth.target_image(H, W).to(dev)
 tiles_y = (H + 15) // 16
-for R in (1, 2, 4, 8):
-    plan = band_plan(tiles_y, R)
-    for r in sorted({0, R // 2}):
-        pipe = FramePipeline(N, H, W, kind=kind, device=dev, rows=plan[r])
-        for _ in range(10):
-            pipe.forward(*inputs)
+
+
+def timed(fn, warmup=10):
+    """Median over chunks of 20 calls (a fit's first steps include one-off list sizing)."""
+    for _ in range(warmup):
+        fn()
+    chunks = []
+    for _ in range(max(1, args.reps // 20)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(200):
-            pipe.forward(*inputs)
+        for _ in range(20):
+            fn()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 200 * 1e3
-        tp = time.perf_counter()
-        for _ in range(200):
-            pipe.project(*inputs[:3])
-        torch.cuda.synchronize()
-        mp = (time.perf_counter() - tp) / 200 * 1e3
-        print(f"R={R} rank={r} rows={plan[r]} forward {ms * 1e3:.1f} us  (projection alone "
-              f"{mp * 1e3:.1f} us)", flush=True)
+        chunks.append((time.perf_counter() - t0) / 20 * 1e6)
+    return sorted(chunks)[len(chunks) // 2]
+
+
+out = {"frame": f"{W}x{H}, {N} Gaussians", "ranks": {}}
+whole = None
+for R in (1, 2, 4, 8):
+    plan = band_plan(tiles_y, R)
+    worst = {"forward_us": 0.0, "projection_us": 0.0, "fwd_bwd_us": 0.0, "fit_step_us": 0.0}
+    for r in sorted({0, R // 2}):
+        pipe = FramePipeline(N, H, W, device=dev, rows=plan[r])
+        y0, y1 = band_pixels(plan, r, H)
+        v_band = v_img[y0:y1].contiguous()
+        f = timed(lambda: pipe.forward(*inputs))
+        p = timed(lambda: pipe.project(*inputs[:3]))
+        pipe.forward(*inputs)
+        fb = timed(lambda: (pipe.forward(*inputs), pipe.backward(*inputs, v_band)))
+        del pipe
+        # the fused fitting step of the band (gi2d_fit_raster + gi2d_fit_tail; the all-reduce of
+        # 9 N floats between them is not part of a one-GPU figure)
+        torch.manual_seed(1)
+        fit = ShardedFitter(N, H, W, "cholesky", r, R, dev, rows=plan[r])
+        fit.fit.ws.reserve(256)   # (no list growth -- a reallocation -- inside the timed steps)
+        if args.fit_ppl:
+            fit.fit.ws.set_raster_ppl(args.fit_ppl)
+        ft = timed(lambda: fit.step(gt), warmup=40)
+        del fit
+        worst = {"forward_us": max(worst["forward_us"], f),
+                 "projection_us": max(worst["projection_us"], p),
+                 "fwd_bwd_us": max(worst["fwd_bwd_us"], fb),
+                 "fit_step_us": max(worst["fit_step_us"], ft)}
+    if R == 1:
+        whole = dict(worst)
+    worst["forward_speedup"] = whole["forward_us"] / worst["forward_us"]
+    worst["fwd_bwd_speedup"] = whole["fwd_bwd_us"] / worst["fwd_bwd_us"]
+    worst["fit_step_speedup"] = whole["fit_step_us"] / worst["fit_step_us"]
+    out["ranks"][str(R)] = {k: round(v, 2) for k, v in worst.items()}
+    print(f"R={R}: band forward {worst['forward_us']:.1f} us (projection alone "
+          f"{worst['projection_us']:.1f}), forward+backward {worst['fwd_bwd_us']:.1f} us; "
+          f"fused fitting step {worst['fit_step_us']:.1f} us; speed-up "
+          f"{worst['forward_speedup']:.2f}x / {worst['fwd_bwd_speedup']:.2f}x / "
+          f"{worst['fit_step_speedup']:.2f}x", flush=True)
+print(json.dumps(out))
