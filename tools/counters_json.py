@@ -1,4 +1,4 @@
-"""Counter passes of tools/gpu_profiles_r02.sh -> profiles/r02_counters.json (per-launch averages
+"""Counter passes of tools/gpu_profiles_r0N.sh -> profiles/<file> (default r02_counters.json; per-launch averages
 of the batch kernels of the headline command; bench.py quotes them with their source).
 
 HBM bytes as the MI355X guide prescribes: the counters are in KiB; on gfx950 FETCH_SIZE reports
@@ -13,6 +13,7 @@ import sys
 from collections import defaultdict
 
 root, key, source = sys.argv[1], sys.argv[2], sys.argv[3]
+dst_name = sys.argv[4] if len(sys.argv) > 4 else "r02_counters.json"
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "**", "pmc_*_counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
@@ -40,12 +41,18 @@ for tag, part in (("raster_fwd", r"rasterize_sum_fwd_kernel<true, false, 1, \d, 
         out[tag + "_write_bytes"] = w * 1024
         out[tag + "_hbm_bytes"] = f * 1024 * 2 + w * 1024
     for c, name in (("SQ_INSTS_VALU", "valu_instr"), ("SQ_INSTS_SALU", "salu_instr"),
-                    ("SQ_INSTS_LDS", "lds_instr"), ("SQ_WAVES", "waves")):
+                    ("SQ_INSTS_LDS", "lds_instr"), ("SQ_WAVES", "waves"),
+                    ("SQ_WAVE_CYCLES", "wave_quad_cycles"), ("SQ_WAIT_ANY", "wait_any_quad_cycles"),
+                    ("SQ_WAIT_INST_ANY", "wait_inst_any_quad_cycles"),
+                    ("SQ_ACTIVE_INST_ANY", "active_inst_any_quad_cycles"),
+                    ("SQ_INST_CYCLES_SALU", "salu_quad_cycles"),
+                    ("SQ_ACTIVE_INST_LDS", "active_inst_lds_quad_cycles"),
+                    ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles")):
         v = avg(part, c)
         if v is not None:
             out[tag + "_" + name] = v
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                   "r02_counters.json")
+                   dst_name)
 data = json.load(open(dst)) if os.path.exists(dst) else {}
 data[key] = out
 json.dump(data, open(dst, "w"), indent=1)
