@@ -867,7 +867,7 @@ def main():
     roofline = roofline_entry("raster_fwd", timing, B * N, I_8d, I_held, B * P, B * T)
     roofline["kernel"] = "rasterize_sum_fwd_kernel (one launch renders the step's %d frames)" % B
     # HBM traffic and instruction counts of the same launch come from counters-only rocprofv3
-    # passes (a separate run of this command; tools/gpu_counters.sh): kept with their source
+    # passes (a separate run of this command; tools/gpu_profiles_r03.sh): kept with their source
     roofline["traffic"] = None
     cpath = os.path.join(ROOT, "profiles", "r03_counters.json")
     if os.path.exists(cpath):
