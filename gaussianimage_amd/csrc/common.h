@@ -118,3 +118,38 @@ __device__ __forceinline__ int xcd_tile(int bid, int T)
     const int q = T >> 3, r = T & 7, x = bid & 7, k = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
+
+// ---- selects made of 2-cycle instructions ------------------------------------------------------
+// clamp(a * b + c) to [0, 1] in one instruction
+__device__ __forceinline__ float fma_clamp01(float a, float b, float c)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// clamp(a - b) to [0, 1] in one instruction
+__device__ __forceinline__ float sub_clamp01(float a, float b)
+{
+    float r;
+    asm("v_sub_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// What the loops need of the conventions, in registers (a constant read from an SGPR would make
+// its instruction a 4-cycle one): 1 where alpha >= alpha_min, 0 below, is
+// clamp(alpha * step_scale + step_bias).
+struct StepConsts {
+    float step_scale, step_bias;
+};
+
+__device__ __forceinline__ StepConsts step_consts(const gi2d_conv &cv)
+{
+    StepConsts k;
+    k.step_scale = 1.152921504606846976e18f;  // 2^60: one ulp of alpha_min becomes >= 1
+    // (alpha - below(alpha_min)) * 2^60 is <= 0 for alpha < alpha_min and >= 2^28 otherwise
+    k.step_bias = cv.alpha_min > 0.f
+                      ? -__int_as_float(__float_as_int(cv.alpha_min) - 1) * k.step_scale
+                      : 1.0f;
+    return k;
+}

@@ -280,10 +280,10 @@ __device__ __forceinline__ void fit_bwd_64(
 // PPL = 1: 256 lanes per tile; PPL = 4: one wave per tile (the forward renders four pixels per
 // lane, the backward gives each entry 4 to 16 lanes and has no work-piece path).
 template <bool FINALIZE, int PPL, bool PACKED>
-// (8 waves per SIMD for the 256-lane form, as in rasterize_sum_bwd_kernel; the one-wave form is
+// (7 waves per SIMD for the 256-lane form, as in rasterize_sum_bwd_kernel; the one-wave form is
 // limited by its LDS)
 __global__ __launch_bounds__(256 / PPL)
-__attribute__((amdgpu_waves_per_eu(PPL == 1 ? 8 : 5, 8))) void
+__attribute__((amdgpu_waves_per_eu(PPL == 1 ? 7 : 5, 8))) void
 fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
                   const int *__restrict__ radii, const float *__restrict__ conics,
                   const float *__restrict__ colors, const float *__restrict__ opacity,

@@ -21,9 +21,10 @@
 // search (lists ascend in Gaussian id).
 // ------------------------------------------------------------------------------------------
 
-// (8 waves per SIMD: the two paths together would otherwise take 66 registers and lose a
-// workgroup per CU, which the latency-bound short-list tiles feel)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void
+// (at least 7 waves per SIMD, i.e. at most 72 registers: the two paths with their plain and
+// general pixel loops take 71; held to 64 for an eighth workgroup per CU they spill, which costs
+// more than the workgroup gains -- measured at 768x512 / 30 000 and 1020x768 / 50 000)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void
 rasterize_sum_bwd_kernel(
     const int *__restrict__ tile_len, const int *__restrict__ seg, int C,
     const float *__restrict__ xys, const int *__restrict__ radii,

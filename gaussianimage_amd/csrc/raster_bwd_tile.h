@@ -3,6 +3,7 @@
 #pragma once
 #include "gather.h"
 #include "host.h"
+#include "projection.h"
 #include "support.h"
 #include "tiles.h"
 
@@ -55,6 +56,80 @@ __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
+// ---- the pixel loop of an entry ---------------------------------------------------------------
+// Vector instructions do not all issue at the same rate on this part (measured,
+// tools/micro/op_rates.hip): v_fma / v_mul / v_add / v_sub_f32, v_mov, v_add_u32 and v_and_b32
+// take 2 cycles per wave64 instruction; compares, v_cndmask, v_min / v_max, conversions, shifts
+// and anything with an SGPR operand take 4; v_exp_f32 takes 8.  The loop below therefore walks the
+// rectangle in FLOATING POINT (the pixel coordinates are small integers, exact in fp32) and
+// replaces every select by a multiplication with a 0/1 factor made by one v_fma with the clamp
+// modifier, so that a step of a plain entry is 2-cycle instructions but for the exponential and
+// the loop's own compare.
+
+// Pixels k0, k0 + STRIDE, ... < k_end of the rectangle of width w whose first row starts at x0
+// and whose last column is x1 (tile coordinates), pixel k = (x0 + k % w, y0 + k / w); (x, y) is
+// pixel k0.  Adds the lane's share of the nine partial sums: [0..1] sum vs*d, [2..4] the second
+// moments of vs, [5..7] sum alpha*v_out, [8] sum exp * v_alpha.  PLAIN: the entry's exponent is
+// never positive and its alpha never reaches the cap (projection.h), so alpha = opacity * exp.
+template <int STRIDE, bool PLAIN>
+__device__ __forceinline__ void bwd_pixels(float (&acc)[PART_STRIDE], int k0, int k_end, int x,
+                                           int y, int x1, int w, float gx, float gy, float ox,
+                                           float oy, float a, float b, float c, float op, float cr,
+                                           float cg, float cb, const float4 *s_v,
+                                           const gi2d_conv &cv, const StepConsts &kc)
+{
+    // STRIDE / w and STRIDE % w for w in 1..16 from the hardware reciprocal (exact here: the
+    // quotient's fractional part is a multiple of 1/w, well clear of the 1-ulp error)
+    const float wf = (float)w;
+    const float sy = floorf((float)STRIDE * __builtin_amdgcn_rcpf(wf) + 1.0e-3f);
+    const float sx = (float)STRIDE - sy * wf;
+    const float x1f = (float)x1, nwf = -wf;
+    float fx = (float)x, fy = (float)y;
+    const float pa = (-0.5f * LOG2E) * a, pb = (-LOG2E) * b, pc = (-0.5f * LOG2E) * c;
+    const char *v_base = reinterpret_cast<const char *>(s_v);
+    for (int k = k0; k < k_end; k += STRIDE) {
+        const float dx = gx - (ox + fx), dy = gy - (oy + fy);
+        const float p = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
+        const float ex = __builtin_amdgcn_exp2f(p);
+        const float oe = op * ex;
+        // byte offset of v[y][x] (16 bytes each, 16 per row): 2^23 + 256*y + 16*x is exact, and
+        // the low bits of its mantissa are the offset
+        const float af = __builtin_fmaf(fy, 256.0f, __builtin_fmaf(fx, 16.0f, 8388608.0f));
+        const float4 v = *reinterpret_cast<const float4 *>(v_base + (__float_as_int(af) & 0xffff));
+        const float v_alpha = __builtin_fmaf(cb, v.z, __builtin_fmaf(cg, v.y, cr * v.x));
+        float am, va;
+        if (PLAIN) {
+            const float on = fma_clamp01(oe, kc.step_scale, kc.step_bias);
+            am = oe * on;
+            va = v_alpha * on;
+        } else {
+            const float alpha = fminf(cv.alpha_cap, oe);
+            const bool on = !(p > 0.f || alpha < cv.alpha_min);
+            am = on ? alpha : 0.f;
+            const bool live = on && !(oe > cv.alpha_cap);  // a capped alpha is a constant
+            va = live ? v_alpha : 0.f;
+        }
+        acc[5] = __builtin_fmaf(am, v.x, acc[5]);
+        acc[6] = __builtin_fmaf(am, v.y, acc[6]);
+        acc[7] = __builtin_fmaf(am, v.z, acc[7]);
+        const float vs = -oe * va;
+        acc[8] = __builtin_fmaf(ex, va, acc[8]);
+        // moments of vs over the rectangle; the conic enters once, after the loop
+        const float hx = vs * dx, hy = vs * dy;
+        acc[0] += hx;
+        acc[1] += hy;
+        acc[2] = __builtin_fmaf(hx, dx, acc[2]);
+        acc[3] = __builtin_fmaf(hx, dy, acc[3]);
+        acc[4] = __builtin_fmaf(hy, dy, acc[4]);
+        // next pixel: STRIDE further along the rows (at most one wrap: sx < w)
+        fx += sx;
+        fy += sy;
+        const float wrap = sub_clamp01(fx, x1f);  // 1 past the last column (by >= 1), else 0
+        fx = __builtin_fmaf(nwf, wrap, fx);
+        fy += wrap;
+    }
+}
+
 // The batches of one tile with LPE lanes per list entry, in a workgroup of NT lanes (NT / LPE
 // entries per batch).
 template <int LPE, int NT = 256>
@@ -73,6 +148,7 @@ __device__ __forceinline__ void bwd_tile(
     const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
     const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
     const int q = tid & (LPE - 1);
+    const StepConsts kc = step_consts(cv);
     for (int base = 0; base < n_raw; base += EPB) {
         const int e = base + tid / LPE;
         float acc[PART_STRIDE];
@@ -94,46 +170,18 @@ __device__ __forceinline__ void bwd_tile(
             const int w = x1 - x0 + 1, h = y1 - y0 + 1;
             const int cnt = (w > 0 && h > 0) ? w * h : 0;
             touched = cnt > 0;
-            // The lanes of the group take the rectangle's pixels round-robin.  LPE / w and
-            // q / w for w in 1..16 from the hardware reciprocal (exact here: the quotients'
-            // fractional parts are multiples of 1/w, well clear of the 1-ulp error).
+            // The lanes of the group take the rectangle's pixels round-robin.  q / w for w in
+            // 1..16 from the hardware reciprocal (exact here: the quotient's fractional part is
+            // a multiple of 1/w, well clear of the 1-ulp error).
             const float rw = __builtin_amdgcn_rcpf((float)max(w, 1));
-            const int step_y = cnt ? (int)((float)LPE * rw + 1.0e-3f) : 0;
-            const int step_x = cnt ? LPE - step_y * w : 0;
             const int qy = (int)(((float)q + 0.5f) * rw);
-            int x = x0 + q - qy * w, y = y0 + qy;
-            const float pa = (-0.5f * LOG2E) * a, pb = (-LOG2E) * b, pc = (-0.5f * LOG2E) * c;
-            for (int k = q; k < cnt; k += LPE) {
-                const float dx = gx - (ox + (float)x), dy = gy - (oy + (float)y);
-                const float p = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
-                const float ex = __builtin_amdgcn_exp2f(p);
-                const float oe = op * ex;
-                const float alpha = fminf(cv.alpha_cap, oe);
-                const bool on = !(p > 0.f || alpha < cv.alpha_min);
-                const float4 v = s_v[y * GI2D_BLOCK + x];
-                const float am = on ? alpha : 0.f;
-                acc[5] = __builtin_fmaf(am, v.x, acc[5]);
-                acc[6] = __builtin_fmaf(am, v.y, acc[6]);
-                acc[7] = __builtin_fmaf(am, v.z, acc[7]);
-                const float v_alpha = __builtin_fmaf(cb, v.z, __builtin_fmaf(cg, v.y, cr * v.x));
-                const bool live = on && !(oe > cv.alpha_cap);  // a capped alpha is a constant
-                const float va = live ? v_alpha : 0.f;
-                const float vs = -oe * va;
-                acc[8] = __builtin_fmaf(ex, va, acc[8]);
-                // moments of vs over the rectangle; the conic enters once, after the loop
-                const float hx = vs * dx, hy = vs * dy;
-                acc[0] += hx;
-                acc[1] += hy;
-                acc[2] = __builtin_fmaf(hx, dx, acc[2]);
-                acc[3] = __builtin_fmaf(hx, dy, acc[3]);
-                acc[4] = __builtin_fmaf(hy, dy, acc[4]);
-                x += step_x;
-                y += step_y;
-                if (x > x1) {
-                    x -= w;
-                    ++y;
-                }
-            }
+            const int x = x0 + q - qy * w, y = y0 + qy;
+            if (plain_entry(a, b, c, op, cv.alpha_cap))
+                bwd_pixels<LPE, true>(acc, q, cnt, x, y, x1, w, gx, gy, ox, oy, a, b, c, op, cr, cg,
+                                      cb, s_v, cv, kc);
+            else
+                bwd_pixels<LPE, false>(acc, q, cnt, x, y, x1, w, gx, gy, ox, oy, a, b, c, op, cr,
+                                       cg, cb, s_v, cv, kc);
             // v_xy = sum vs * (conic . d) = conic . (sum vs * d); v_conic = (1/2, 1, 1/2) * moments
             const float m0 = acc[0], m1 = acc[1];
             acc[0] = __builtin_fmaf(b, m1, a * m0);
@@ -189,6 +237,7 @@ __device__ __forceinline__ void bwd_tile_pieces(
     const int y_hi = min(GI2D_BLOCK, H - ty * GI2D_BLOCK) - 1;
     const float ox = (float)(tx * GI2D_BLOCK) + cv.pixel_offset;
     const float oy = (float)(ty * GI2D_BLOCK) + cv.pixel_offset;
+    const StepConsts kc = step_consts(cv);
     for (int base = 0; base < n_raw; base += EB) {
         const int n = min(EB, n_raw - base);
         // ---- A: stage entry `tid` ----------------------------------------------------------
@@ -206,8 +255,10 @@ __device__ __forceinline__ void bwd_tile_pieces(
             const int rect = cnt ? (x0 | (x1 << 8) | (y0 << 16) | (y1 << 24)) : 0;
             s_r0[tid] = make_float4(gx, gy, a, b);
             s_r1[tid] = make_float4(c, op, colors[3 * gid], colors[3 * gid + 1]);
-            s_r2[tid] = make_float4(colors[3 * gid + 2], __int_as_float(gid), __int_as_float(rad),
-                                    __int_as_float(rect));
+            // (bit 31 of the staged radius: a general entry, see bwd_pixels)
+            const int general = plain_entry(a, b, c, op, cv.alpha_cap) ? 0 : (int)0x80000000;
+            s_r2[tid] = make_float4(colors[3 * gid + 2], __int_as_float(gid),
+                                    __int_as_float(rad | general), __int_as_float(rect));
         }
         // ---- B: pieces ---------------------------------------------------------------------
         // The batch's pixels are cut into about QUADS pieces per EB / 4 entries (at most
@@ -260,43 +311,16 @@ __device__ __forceinline__ void bwd_tile_pieces(
             const float rw = __builtin_amdgcn_rcpf((float)w);
             const int k0 = k_beg + q;
             const int ky = (int)(((float)k0 + 0.5f) * rw);
-            int x = x0 + k0 - ky * w, y = y0 + ky;
-            const int step_y = (int)(4.0f * rw + 1.0e-3f), step_x = 4 - step_y * w;
-            const float pa = (-0.5f * LOG2E) * a, pb = (-LOG2E) * b, pc = (-0.5f * LOG2E) * c;
+            const int x = x0 + k0 - ky * w, y = y0 + ky;
             float acc[PART_STRIDE];
 #pragma unroll
             for (int k = 0; k < PART_STRIDE; ++k) acc[k] = 0.f;
-            for (int k = k0; k < k_end; k += 4) {
-                const float dx = gx - (ox + (float)x), dy = gy - (oy + (float)y);
-                const float pp = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
-                const float ex = __builtin_amdgcn_exp2f(pp);
-                const float oe = op * ex;
-                const float alpha = fminf(cv.alpha_cap, oe);
-                const bool on = !(pp > 0.f || alpha < cv.alpha_min);
-                const float4 v = s_v[y * GI2D_BLOCK + x];
-                const float am = on ? alpha : 0.f;
-                acc[5] = __builtin_fmaf(am, v.x, acc[5]);
-                acc[6] = __builtin_fmaf(am, v.y, acc[6]);
-                acc[7] = __builtin_fmaf(am, v.z, acc[7]);
-                const float v_alpha = __builtin_fmaf(cb, v.z, __builtin_fmaf(cg, v.y, cr * v.x));
-                const bool live = on && !(oe > cv.alpha_cap);  // a capped alpha is a constant
-                const float va = live ? v_alpha : 0.f;
-                const float vs = -oe * va;
-                acc[8] = __builtin_fmaf(ex, va, acc[8]);
-                // moments of vs over the rectangle; the conic enters once, in step D
-                const float hx = vs * dx, hy = vs * dy;
-                acc[0] += hx;
-                acc[1] += hy;
-                acc[2] = __builtin_fmaf(hx, dx, acc[2]);
-                acc[3] = __builtin_fmaf(hx, dy, acc[3]);
-                acc[4] = __builtin_fmaf(hy, dy, acc[4]);
-                x += step_x;
-                y += step_y;
-                if (x > x1) {
-                    x -= w;
-                    ++y;
-                }
-            }
+            if (__float_as_int(r2.z) >= 0)
+                bwd_pixels<4, true>(acc, k0, k_end, x, y, x1, w, gx, gy, ox, oy, a, b, c, op, cr, cg,
+                                    cb, s_v, cv, kc);
+            else
+                bwd_pixels<4, false>(acc, k0, k_end, x, y, x1, w, gx, gy, ox, oy, a, b, c, op, cr,
+                                     cg, cb, s_v, cv, kc);
 #pragma unroll
             for (int k = 0; k < PART_STRIDE; ++k) acc[k] = quad_sum(acc[k]);
             if (q == 0) {
@@ -308,7 +332,7 @@ __device__ __forceinline__ void bwd_tile_pieces(
         // ---- D: entry `tid` adds its pieces and stores -------------------------------------
         if (tid < n) {
             const float4 r0 = s_r0[tid], r1 = s_r1[tid], r2 = s_r2[tid];
-            const int gid = __float_as_int(r2.y), rad = __float_as_int(r2.z);
+            const int gid = __float_as_int(r2.y), rad = __float_as_int(r2.z) & 0x7fffffff;
             // index of this tile in the Gaussian's own (band-clipped) tile box: the first GSLOTS
             // tiles write to the Gaussian's slots (with the stamp), the others to the tile's slab
             TileBox box = tile_box(r0.x, r0.y, (float)rad, tiles_x, tiles_y);
