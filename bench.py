@@ -881,9 +881,10 @@ def main():
                     "peak_instr_per_s": VALU_PEAK_INSTR_S, "source": c.get("source"),
                     "frac": c["raster_fwd_valu_instr"] / VALU_PEAK_INSTR_S /
                     (timing["avg_launch_ms"] * 1e-3),
-                    "note": "the pair loop's own ceiling is lower than the issue peak: an "
-                            "evaluation is 13 two-cycle instructions and one v_exp_f32 of 16 "
-                            "cycles (profiles/r03_experiments/README.md)"}
+                    "note": "the peak is that of 2-cycle instructions (fma/mul/add); compares, "
+                            "selects and SGPR-operand forms take 4 cycles, v_exp_f32 8 or more: "
+                            "one pair evaluation is about 40 cycles "
+                            "(profiles/r03_experiments/README.md)"}
         except Exception:
             pass
 
