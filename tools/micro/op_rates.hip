@@ -59,6 +59,20 @@
 #define OP_AND_LIT(i) "v_and_b32 %" #i ", 0xffff, %" #i "\n"
 #define OP_MUL_NEG(i) "v_mul_f32_e64 %" #i ", %" #i ", -%8\n"
 #define OP_SUB_CLAMP(i) "v_sub_f32_e64 %" #i ", %" #i ", %8 clamp\n"
+#define OP_MUL_LO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
+#define OP_MUL_HI(i) "v_mul_hi_u32 %" #i ", %" #i ", %8\n"
+#define OP_MUL_U24(i) "v_mul_u32_u24 %" #i ", %" #i ", %8\n"
+#define OP_LSHL_ADD(i) "v_lshl_add_u32 %" #i ", %" #i ", 4, %8\n"
+#define OP_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
+#define OP_ADD_CO(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n"
+#define OP_ADDC_CO(i) "v_addc_co_u32 %" #i ", vcc, %" #i ", %8, vcc\n"
+#define OP_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 1, 2\n"
+#define OP_FLOOR(i) "v_floor_f32 %" #i ", %" #i "\n"
+#define OP_SQRT(i) "v_sqrt_f32 %" #i ", %" #i "\n"
+#define OP_LOG(i) "v_log_f32 %" #i ", %" #i "\n"
+#define OP_MAX_I32(i) "v_max_i32 %" #i ", %" #i ", %8\n"
+#define OP_OR(i) "v_or_b32 %" #i ", %" #i ", %8\n"
+#define OP_SUB_U32(i) "v_sub_u32 %" #i ", %" #i ", %8\n"
 #define OP_MAX_ZERO(i) "v_max_f32 %" #i ", 0, %" #i "\n"
 
 KERNEL(k_fma, OP_FMA, "")
@@ -89,6 +103,44 @@ KERNEL(k_fmac_lit, OP_FMAC_LIT, "")
 KERNEL(k_and_lit, OP_AND_LIT, "")
 KERNEL(k_mul_neg, OP_MUL_NEG, "")
 KERNEL(k_sub_clamp, OP_SUB_CLAMP, "")
+KERNEL(k_mul_lo, OP_MUL_LO, "")
+KERNEL(k_mul_hi, OP_MUL_HI, "")
+KERNEL(k_mul_u24, OP_MUL_U24, "")
+KERNEL(k_lshl_add, OP_LSHL_ADD, "")
+KERNEL(k_add3, OP_ADD3, "")
+KERNEL(k_add_co, OP_ADD_CO, "")
+KERNEL(k_addc_co, OP_ADDC_CO, "")
+KERNEL(k_bfe, OP_BFE, "")
+KERNEL(k_floor, OP_FLOOR, "")
+KERNEL(k_sqrt, OP_SQRT, "")
+KERNEL(k_log, OP_LOG, "")
+KERNEL(k_max_i32, OP_MAX_I32, "")
+KERNEL(k_or, OP_OR, "")
+KERNEL(k_sub_u32, OP_SUB_U32, "")
+
+// 64-bit forms: four independent register pairs, 16 instructions per trip
+#define KERNEL64(NAME, BODY)                                                                    \
+    __global__ void NAME(float *out, int iters, float m, float c)                               \
+    {                                                                                           \
+        unsigned long long a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;             \
+        unsigned mi = __float_as_uint(m), ci = __float_as_uint(c);                              \
+        for (int i = 0; i < iters; ++i) {                                                       \
+            asm volatile(BODY BODY BODY BODY                                                    \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                               \
+                         : "v"(mi), "v"(ci)                                                     \
+                         : "vcc", "s20", "s21");                                                \
+        }                                                                                       \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3);                \
+    }
+#define B_MAD_U64 "v_mad_u64_u32 %0, s[20:21], %4, %5, %0\n v_mad_u64_u32 %1, s[20:21], %4, %5, %1\n" \
+                  "v_mad_u64_u32 %2, s[20:21], %4, %5, %2\n v_mad_u64_u32 %3, s[20:21], %4, %5, %3\n"
+#define B_LSHL_ADD_U64 "v_lshl_add_u64 %0, %0, 2, %1\n v_lshl_add_u64 %1, %1, 2, %2\n" \
+                       "v_lshl_add_u64 %2, %2, 2, %3\n v_lshl_add_u64 %3, %3, 2, %0\n"
+#define B_LSHL_B64 "v_lshlrev_b64 %0, 1, %0\n v_lshlrev_b64 %1, 1, %1\n v_lshlrev_b64 %2, 1, %2\n" \
+                   "v_lshlrev_b64 %3, 1, %3\n"
+KERNEL64(k_mad_u64, B_MAD_U64)
+KERNEL64(k_lshl_add_u64, B_LSHL_ADD_U64)
+KERNEL64(k_lshl_b64, B_LSHL_B64)
 KERNEL(k_cndmask_s, OP_CNDMASK_S, "v_cmp_lt_f32 s[20:21], %8, %9\n")
 KERNEL(k_fma_clamp, OP_FMA_CLAMP, "")
 KERNEL(k_mul_sgpr, OP_MUL_SGPR, "s_mov_b32 s20, 0x3f7fbe77\n")
@@ -210,10 +262,39 @@ int main()
         {"v_mul_f32 (sgpr operand)", k_mul_sgpr}, {"v_fmamk_f32 (literal)", k_fmamk},
         {"v_fmac_f32 (literal)", k_fmac_lit}, {"v_and_b32 (literal)", k_and_lit},
         {"v_mul_f32_e64 (neg modifier)", k_mul_neg}, {"v_sub_f32_e64 clamp", k_sub_clamp},
+        {"v_mul_lo_u32", k_mul_lo}, {"v_mul_hi_u32", k_mul_hi}, {"v_mul_u32_u24", k_mul_u24},
+        {"v_lshl_add_u32", k_lshl_add}, {"v_add3_u32", k_add3}, {"v_add_co_u32", k_add_co},
+        {"v_addc_co_u32", k_addc_co}, {"v_bfe_u32", k_bfe}, {"v_floor_f32", k_floor},
+        {"v_sqrt_f32", k_sqrt}, {"v_log_f32", k_log}, {"v_max_i32", k_max_i32}, {"v_or_b32", k_or},
+        {"v_sub_u32", k_sub_u32},
     };
     for (auto &e : ks)
         for (int w : {2, 8})
             if (run(e.name, e.k, d_out, cus, w, 4000)) return 1;
+    struct { const char *name; kern_t k; } k64[] = {
+        {"v_mad_u64_u32", k_mad_u64}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_lshlrev_b64", k_lshl_b64}};
+    for (auto &e : k64)
+        for (int w : {2, 8}) {
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0));
+            CHECK(hipEventCreate(&e1));
+            const int blocks = cus * w, iters = 4000;
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, d_out, iters, 0.999f, 0.001f);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            const double rate = 16.0 * iters * blocks * 4 / (best * 1e-3);
+            printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.4f, \"wave_instr_per_s\": %.4e, "
+                   "\"simd_cycles_per_instr_at_2.4GHz\": %.2f}\n",
+                   e.name, w, best, rate, (double)cus * 4 * 2.4e9 / rate);
+            fflush(stdout);
+        }
     // (the evaluation kernels: 2 evaluations per trip; the rate is per 32 "instructions" of the
     // run() bookkeeping, i.e. multiply the cycles by 32 / 2 for cycles per evaluation)
     const float amin = 1.f / 255.f, below = nextafterf(amin, 0.f);
