@@ -201,13 +201,14 @@ __global__ __launch_bounds__(256) void fit_tail_kernel(
 // work-piece buffers
 #define FIT_POOL_BWD_INTS \
     (3 * 4 * BWD_BATCH + (BWD_BATCH + 4) + BWD_MAX_PIECES * PART_STRIDE + BWD_MAX_PIECES / 4)
-// ... of the one-wave form (32 entries per batch, 64 pieces)
-#define FIT64_POOL_BWD_INTS (3 * 4 * 32 + (32 + 4) + 64 * PART_STRIDE + 64 / 4)
+// ... of the one-wave form (32 entries per batch, 48 pieces)
+#define FIT64_POOL_BWD_INTS \
+    (3 * 4 * 32 + (32 + 4) + BWD64_MAX_PIECES * PART_STRIDE + BWD64_MAX_PIECES / 4)
 
 // The backward of one tile inside the fused kernel, workgroup of 256 lanes: direct paths for
 // short lists, equal work pieces beyond.
 __device__ __forceinline__ void fit_bwd_256(
-    int *pool, const float4 *s_v, int *s_w, const int *lst, int gid_first, int n_raw,
+    int *pool, const float *s_v, int *s_w, const int *lst, int gid_first, int n_raw,
     size_t slot0, int tx, int ty, const float *__restrict__ xys, const int *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
@@ -241,7 +242,7 @@ __device__ __forceinline__ void fit_bwd_256(
 // ... and of a single wave (sparse frames: many tiles with a handful of Gaussians each): the
 // fewer entries, the more lanes each gets.
 __device__ __forceinline__ void fit_bwd_64(
-    int *pool, const float4 *s_v, const int *lst, int gid_first, int n_raw, size_t slot0, int tx,
+    int *pool, const float *s_v, const int *lst, int gid_first, int n_raw, size_t slot0, int tx,
     int ty, const float *__restrict__ xys, const int *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
@@ -269,7 +270,8 @@ __device__ __forceinline__ void fit_bwd_64(
         float4 *s_r1 = s_r0 + 32, *s_r2 = s_r1 + 32;
         int *s_start = reinterpret_cast<int *>(s_r2 + 32);
         float *s_piece = reinterpret_cast<float *>(s_start + 32 + 4);
-        unsigned char *s_owner = reinterpret_cast<unsigned char *>(s_piece + 64 * PART_STRIDE);
+        unsigned char *s_owner =
+            reinterpret_cast<unsigned char *>(s_piece + BWD64_MAX_PIECES * PART_STRIDE);
         bwd_tile_pieces<64>(lst, gid_first, n_raw, slot0, tx, ty, s_v, s_r0, s_r1, s_r2, s_start,
                             nullptr, s_piece, s_owner, xys, radii, conics, colors, opacity, H, W,
                             tiles_x, tiles_y, row0, cv, cull, partials, gslots, gslot_n, stamp);
@@ -283,7 +285,7 @@ template <bool FINALIZE, int PPL, bool PACKED>
 // (7 waves per SIMD for the 256-lane form, as in rasterize_sum_bwd_kernel; the one-wave form is
 // limited by its LDS)
 __global__ __launch_bounds__(256 / PPL)
-__attribute__((amdgpu_waves_per_eu(PPL == 1 ? 7 : 5, 8))) void
+__attribute__((amdgpu_waves_per_eu(PPL == 1 ? 7 : 6, 8))) void
 fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
                   const int *__restrict__ radii, const float *__restrict__ conics,
                   const float *__restrict__ colors, const float *__restrict__ opacity,
@@ -321,7 +323,7 @@ fit_raster_kernel(int *tile_count, int *tile_len, int *seg, int C, const float *
         PPL == 1 ? (FIT_POOL_BWD_INTS > FWD_INTS + NT ? FIT_POOL_BWD_INTS : FWD_INTS + NT)
                  : (FIT64_POOL_BWD_INTS > FWD_INTS + NT ? FIT64_POOL_BWD_INTS : FWD_INTS + NT);
     __shared__ __attribute__((aligned(16))) int pool[POOL_INTS];
-    __shared__ float4 s_v[256];   // the tile's loss gradient
+    __shared__ float s_v[VTILE_FLOATS];   // the tile's loss gradient
     __shared__ int s_w[4];
     int *s_sorted = pool + FWD_INTS;
     const int n_raw = fwd_tile<FINALIZE, true, 1, PPL, true, PACKED>(

@@ -33,7 +33,7 @@ rasterize_sum_bwd_kernel(
     int T, gi2d_conv cv, int cull, const float *__restrict__ v_out,
     float *__restrict__ partials, float *__restrict__ gslots, size_t gslot_n, int stamp)
 {
-    __shared__ float4 s_v[256];                       // the tile's v_out
+    __shared__ float s_v[VTILE_FLOATS];               // the tile's v_out
     __shared__ float4 s_r0[BWD_BATCH];                // gx, gy, a, b
     __shared__ float4 s_r1[BWD_BATCH];                // c, opacity, red, green
     __shared__ float4 s_r2[BWD_BATCH];                // blue, id, radius, rectangle (4 x 8 bits)
@@ -63,7 +63,9 @@ rasterize_sum_bwd_kernel(
             v.y = p[1];
             v.z = p[2];
         }
-        s_v[tid] = v;
+        s_v[tid] = v.x;
+        s_v[VTILE_PLANE + tid] = v.y;
+        s_v[2 * VTILE_PLANE + tid] = v.z;
         if (tid < 64) s_first[tid] = gid_first;
     }
     __syncthreads();
@@ -95,12 +97,12 @@ __global__ __launch_bounds__(64) void rasterize_sum_bwd_wave_kernel(
     int T, gi2d_conv cv, int cull, const float *__restrict__ v_out,
     float *__restrict__ partials, float *__restrict__ gslots, size_t gslot_n, int stamp)
 {
-    __shared__ float4 s_v[256];
+    __shared__ float s_v[VTILE_FLOATS];
     __shared__ int s_first[64];
     __shared__ float4 s_r0[32], s_r1[32], s_r2[32];  // the work-piece path's buffers, as above
     __shared__ int s_start[32 + 1];
-    __shared__ float s_piece[64 * PART_STRIDE];
-    __shared__ unsigned char s_owner[64];
+    __shared__ float s_piece[BWD64_MAX_PIECES * PART_STRIDE];
+    __shared__ unsigned char s_owner[BWD64_MAX_PIECES];
     const int tid = threadIdx.x;
     const int t = xcd_tile(blockIdx.x, T);
     const int *lst = seg + (size_t)t * C;
@@ -120,7 +122,9 @@ __global__ __launch_bounds__(64) void rasterize_sum_bwd_wave_kernel(
             v.y = p[1];
             v.z = p[2];
         }
-        s_v[px] = v;
+        s_v[px] = v.x;
+        s_v[VTILE_PLANE + px] = v.y;
+        s_v[2 * VTILE_PLANE + px] = v.z;
     }
     s_first[tid] = gid_first;
     __syncthreads();

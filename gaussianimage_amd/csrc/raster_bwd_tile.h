@@ -7,6 +7,12 @@
 #include "support.h"
 #include "tiles.h"
 
+// The tile's loss gradient in LDS: three planes (red, green, blue) of 256 floats,
+// v[ch * VTILE_PLANE + y * 16 + x] -- 3 KB instead of 4 as float4s, which is what the one-wave
+// forms' occupancy is short of.
+#define VTILE_PLANE 256
+#define VTILE_FLOATS (3 * VTILE_PLANE)
+
 #define BWD_BATCH 128                  // entries per batch of the work-piece path
 // Lists longer than this take the work-piece path.  Measured on MI355X: a 50k-Gaussian fit of a
 // ~1020x768 image spends 37 us per backward in its fitted regime with the threshold at 64, 30 us
@@ -22,6 +28,8 @@
 #define BWD_QUADS 64                   // quads of lanes per workgroup
 #define BWD_MAX_ROUNDS 4               // rounds of BWD_QUADS pieces a batch is cut into, at most
 #define BWD_MAX_PIECES (BWD_QUADS * BWD_MAX_ROUNDS)
+#define BWD64_MAX_ROUNDS 3             // ... of the one-wave form (16 quads)
+#define BWD64_MAX_PIECES (16 * BWD64_MAX_ROUNDS)
 
 // inclusive prefix sum over the NT (256 or 64) lanes of the workgroup (s_w: 4 ints of LDS, unused
 // by a single wave); total in `all`
@@ -75,7 +83,7 @@ template <int STRIDE, bool PLAIN>
 __device__ __forceinline__ void bwd_pixels(float (&acc)[PART_STRIDE], int k0, int k_end, int x,
                                            int y, int x1, int w, float gx, float gy, float ox,
                                            float oy, float a, float b, float c, float op, float cr,
-                                           float cg, float cb, const float4 *s_v,
+                                           float cg, float cb, const float *s_v,
                                            const gi2d_conv &cv, const StepConsts &kc)
 {
     // STRIDE / w and STRIDE % w for w in 1..16 from the hardware reciprocal (exact here: the
@@ -92,10 +100,11 @@ __device__ __forceinline__ void bwd_pixels(float (&acc)[PART_STRIDE], int k0, in
         const float p = __builtin_fmaf(pc * dy, dy, __builtin_fmaf(pb, dy, pa * dx) * dx);
         const float ex = __builtin_amdgcn_exp2f(p);
         const float oe = op * ex;
-        // byte offset of v[y][x] (16 bytes each, 16 per row): 2^23 + 256*y + 16*x is exact, and
-        // the low bits of its mantissa are the offset
-        const float af = __builtin_fmaf(fy, 256.0f, __builtin_fmaf(fx, 16.0f, 8388608.0f));
-        const float4 v = *reinterpret_cast<const float4 *>(v_base + (__float_as_int(af) & 0xffff));
+        // byte offset of pixel (x, y) in a plane (4 bytes each, 16 per row): 2^23 + 64*y + 4*x
+        // is exact, and the low bits of its mantissa are the offset
+        const float af = __builtin_fmaf(fy, 64.0f, __builtin_fmaf(fx, 4.0f, 8388608.0f));
+        const float *vp = reinterpret_cast<const float *>(v_base + (__float_as_int(af) & 0xffff));
+        const float3 v = make_float3(vp[0], vp[VTILE_PLANE], vp[2 * VTILE_PLANE]);
         const float v_alpha = __builtin_fmaf(cb, v.z, __builtin_fmaf(cg, v.y, cr * v.x));
         float am, va;
         if (PLAIN) {
@@ -135,7 +144,7 @@ __device__ __forceinline__ void bwd_pixels(float (&acc)[PART_STRIDE], int k0, in
 template <int LPE, int NT = 256>
 __device__ __forceinline__ void bwd_tile(
     const int *lst, const int *s_first, int n_raw, size_t slot0, int tx, int ty,
-    const float4 *s_v, const float *__restrict__ xys, const int *__restrict__ radii,
+    const float *s_v, const float *__restrict__ xys, const int *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
     const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
@@ -218,19 +227,23 @@ __device__ __forceinline__ void bwd_tile(
 }
 
 // The work-piece path (long lists): the batches of one tile, in a workgroup of NT lanes (256 or
-// 64): NT / 2 entries per batch, NT / 4 quads, at most NT pieces.  s_r0 / s_r1 / s_r2 hold NT / 2
-// float4 each, s_start NT / 2 + 1 ints, s_piece NT x PART_STRIDE floats, s_owner NT bytes.
+// 64): NT / 2 entries per batch, NT / 4 quads, at most 256 or 48 pieces (MAX_PIECES).  s_r0 / s_r1 /
+// s_r2 hold NT / 2 float4 each, s_start NT / 2 + 1 ints, s_piece MAX_PIECES x PART_STRIDE floats,
+// s_owner MAX_PIECES bytes.
 template <int NT = 256>
 __device__ __forceinline__ void bwd_tile_pieces(
     const int *lst, int gid_first, int n_raw, size_t slot0, int tx, int ty,
-    const float4 *s_v, float4 *s_r0, float4 *s_r1, float4 *s_r2, int *s_start, int *s_w,
+    const float *s_v, float4 *s_r0, float4 *s_r1, float4 *s_r2, int *s_start, int *s_w,
     float *s_piece, unsigned char *s_owner, const float *__restrict__ xys, const int *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, int H, int W, int tiles_x, int tiles_y, int row0,
     const gi2d_conv &cv, int cull, float *__restrict__ partials, float *__restrict__ gslots,
     size_t gslot_n, int stamp)
 {
-    constexpr int EB = NT / 2, QUADS = NT / 4, MAX_PIECES = QUADS * BWD_MAX_ROUNDS;
+    // (one wave: at most three rounds -- 48 pieces for 32 entries -- which keeps the form's LDS
+    // within what six workgroups per SIMD may take)
+    constexpr int MAX_ROUNDS = NT == 64 ? BWD64_MAX_ROUNDS : BWD_MAX_ROUNDS;
+    constexpr int EB = NT / 2, QUADS = NT / 4, MAX_PIECES = QUADS * MAX_ROUNDS;
     static_assert(EB == BWD_BATCH || NT == 64, "buffers are sized by BWD_BATCH for 256 lanes");
     const int tid = threadIdx.x, q = tid & 3, quad = tid >> 2;
     const int x_hi = min(GI2D_BLOCK, W - tx * GI2D_BLOCK) - 1;
@@ -268,7 +281,7 @@ __device__ __forceinline__ void bwd_tile_pieces(
         // steps for 128 entries, where 4 rounds of ~17 do).
         int total = 0;
         (void)block_inclusive_scan<NT>(cnt, s_w, total);
-        const int rounds = min(BWD_MAX_ROUNDS, (n + EB / 4 - 1) / (EB / 4));
+        const int rounds = min(MAX_ROUNDS, (n + EB / 4 - 1) / (EB / 4));
         // expected pieces = total / chunk + n / 2 (half a piece of rounding per entry)
         int chunk = max(8, (int)((float)total * __builtin_amdgcn_rcpf(
                                      (float)(QUADS * rounds - (n >> 1)))) + 1);

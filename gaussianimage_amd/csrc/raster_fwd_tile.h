@@ -30,7 +30,7 @@
 // give the same bits.
 //
 // KEEP = true (the fused fitting kernel; with L2): the loss gradient of the tile's pixels stays
-// in LDS (keep_v[ly * 16 + lx]) instead of going to v_img, and a list of up to one batch
+// in LDS (keep_v[ch * 256 + ly * 16 + lx]) instead of going to v_img, and a list of up to one batch
 // (256 / PPL) of ids that this pass sorts (FINALIZE) is also left, sorted, in keep_ids.
 // `smem` holds FWD_LDS_INTS_PER_ENTRY * (256 / PPL) ints (16-byte aligned), `s_x` the extra
 // colour sets' records.  Returns the tile's raw list length.
@@ -40,7 +40,7 @@
 // tensors, turned into the same record while staging.  Same bits either way.
 template <bool FINALIZE, bool L2, int SETS, int PPL, bool KEEP, bool PACKED = false>
 __device__ __forceinline__ int fwd_tile(
-    int *smem, float4 *s_x, float4 *keep_v, int *keep_ids, int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
+    int *smem, float4 *s_x, float *keep_v, int *keep_ids, int *tile_count, int *tile_len, int *seg, int C, const float *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacity, const float *__restrict__ rec,
     const float *__restrict__ background, int H, int W,
@@ -81,6 +81,18 @@ __device__ __forceinline__ int fwd_tile(
         py[u] = (float)i + cv.pixel_offset;
         pix[u] = (size_t)(i - row0 * GI2D_BLOCK) * W + j;
         r[u] = g[u] = b[u] = 0.f;
+    }
+    // The loss epilogue's target values are requested now and used after the pair loops: their
+    // round trip runs under the tile's own work instead of behind it.
+    float gtv[PPL][3];
+    if (L2) {
+        const size_t plane = (size_t)H * W;
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) {
+            const size_t gp = pix[u] + (size_t)(row0 * GI2D_BLOCK) * W;  // index in the full frame
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) gtv[u][ch] = inside[u] ? gt[ch * plane + gp] : 0.f;
+        }
     }
     int *lst = seg + (size_t)t * C;
     // the first batch's id is loaded before the list length is known (a segment always has C
@@ -277,15 +289,13 @@ __device__ __forceinline__ int fwd_tile(
         }
         sq[u] = 0.f;
         if (L2 && inside[u]) {
-            const size_t plane = (size_t)H * W;
-            const size_t gp = pix[u] + (size_t)(row0 * GI2D_BLOCK) * W;  // index in the full frame
-            const float scale = 2.0f / (3.0f * (float)plane);
+            const float scale = 2.0f / (3.0f * (float)((size_t)H * W));
             const float v[3] = {rr, gg, bb};
             float vo[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 const float x = v[ch];
-                const float d = fminf(fmaxf(x, 0.f), 1.f) - gt[ch * plane + gp];
+                const float d = fminf(fmaxf(x, 0.f), 1.f) - gtv[u][ch];
                 sq[u] = __builtin_fmaf(d, d, sq[u]);
                 vo[ch] = (x >= 0.f && x <= 1.f) ? scale * d : 0.f;  // clamp passes its interior
             }
@@ -310,8 +320,10 @@ __device__ __forceinline__ int fwd_tile(
         for (int u = 0; u < PPL; ++u) {
             const int q = wave * PPL + u;
             const int lx = ((q & 1) << 3) + (lane & 7), ly = ((q >> 1) << 3) + (lane >> 3);
-            keep_v[ly * GI2D_BLOCK + lx] =
-                make_float4(keep_vo[u][0], keep_vo[u][1], keep_vo[u][2], 0.f);
+            // (three planes of 256 floats: raster_bwd_tile.h)
+            keep_v[ly * GI2D_BLOCK + lx] = keep_vo[u][0];
+            keep_v[256 + ly * GI2D_BLOCK + lx] = keep_vo[u][1];
+            keep_v[512 + ly * GI2D_BLOCK + lx] = keep_vo[u][2];
         }
     }
     if (L2) {
