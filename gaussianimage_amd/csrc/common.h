@@ -119,6 +119,24 @@ __device__ __forceinline__ int xcd_tile(int bid, int T)
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+// Sum over the 64 lanes of a wave, in the pairing order of an xor butterfly (1, 2, 4, 8, 16, 32)
+// as lane 0 sees it, valid in lane 0: quads and rows by DPP adds (a lane's partner under
+// row_half_mirror / row_mirror is another lane of the partner group, which holds the same sum),
+// the four rows through read-lanes, (r0 + r1) + (r2 + r3).  The same bits as six __shfl_xor
+// steps, without their six dependent LDS round trips.
+__device__ __forceinline__ float wave_sum_lane0(float v)
+{
+    v = quad_sum(v);
+    v = v + dpp_mov<0x141>(v);  // row_half_mirror: lane i <-> 7-i of each 8
+    v = v + dpp_mov<0x140>(v);  // row_mirror: lane i <-> 15-i of each 16
+    const int iv = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // ---- selects made of 2-cycle instructions ------------------------------------------------------
 // clamp(a * b + c) to [0, 1] in one instruction
 __device__ __forceinline__ float fma_clamp01(float a, float b, float c)

@@ -333,9 +333,7 @@ __device__ __forceinline__ int fwd_tile(
         float *s_red = reinterpret_cast<float *>(smem);
 #pragma unroll
         for (int u = 0; u < PPL; ++u) {
-            float v = sq[u];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+            const float v = wave_sum_lane0(sq[u]);
             if (lane == 0) s_red[wave * PPL + u] = v;
         }
         __syncthreads();
