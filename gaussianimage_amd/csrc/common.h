@@ -137,6 +137,29 @@ __device__ __forceinline__ float wave_sum_lane0(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave (every lane active) by DPP adds: shifts by
+// 1, 2, 4, 8 inside each row of 16, then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31
+// into rows 2 and 3.  Six 4-cycle instructions where six __shfl_up steps are six dependent
+// ds_bpermute round trips with their address arithmetic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_shift_int(int v)
+{
+    // (a lane with no source -- shifted in from outside its row, or in a row the mask leaves
+    // out -- receives the 0 given as the old value)
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += dpp_shift_int<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_shift_int<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_shift_int<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_shift_int<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_shift_int<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_shift_int<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ---- selects made of 2-cycle instructions ------------------------------------------------------
 // clamp(a * b + c) to [0, 1] in one instruction
 __device__ __forceinline__ float fma_clamp01(float a, float b, float c)

@@ -271,12 +271,7 @@ __global__ __launch_bounds__(AGG_THREADS) void project_agg_fwd_kernel(
     // exclusive prefix of the counts over the tiles: where each tile's run starts in the stage
     const int lane = tid & 63, wave = tid >> 6;
     const int mine = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]);
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
-    }
+    const int incl = wave_inclusive_scan(mine);
     if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();  // (also: every lane has taken its counts out of the histogram)
     int before = 0, total = 0;
@@ -487,12 +482,7 @@ struct CellGrid {
 __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wave_sum, int &total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    const int incl = wave_inclusive_scan(v);
     if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
     int before = 0;

@@ -37,11 +37,7 @@ template <int NT = 256>
 __device__ __forceinline__ int block_inclusive_scan(int v, int *s_w, int &all)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
+    v = wave_inclusive_scan(v);
     if (NT == 64) {
         all = __builtin_amdgcn_readlane(v, 63);
         return v;
