@@ -27,6 +27,11 @@
 // the memory side, and ~48 Gaussians per tile hammering 32 neighbouring counters of one line
 // made the atomic pass three times slower.
 #define CNT_STRIDE 32
+// ... two per line, in fact: the counters of tiles 2j and 2j+1 (of one frame) are neighbouring
+// words, so that a projection that reserves places for both can do it with ONE 64-bit atomic
+// (returning atomics are what the aggregated list filling waits for: about 2e10 per second on
+// this part whatever their scope).  The words in between stay unused.
+#define CNT_AT(t) (((size_t)((t) & ~1)) * CNT_STRIDE + (size_t)((t) & 1))
 #define LOG2E 1.4426950408889634f
 #define PART_STRIDE 9  // backward partial sums per (tile, Gaussian): v_xy 2, v_conic 3, v_rgb 3, v_op 1
 // Backward pass 1 leaves the partial sums of a Gaussian's first GSLOTS tiles (row-major in its

@@ -42,11 +42,17 @@ __global__ __launch_bounds__(256) void zero_ints_kernel(int *p, int n)
 // synchronous capacity check); otherwise the forward rasteriser does this work itself.
 __global__ __launch_bounds__(WAVE) void finalize_tiles_kernel(int *tile_count, int *tile_len,
                                                               int *seg, int C, DevStatus *status,
-                                                              long long generation)
+                                                              long long generation,
+                                                              int tiles_per_frame)
 {
     __shared__ int s_ids[SORT_LDS_MAX];
-    const int t = blockIdx.x, lane = threadIdx.x;
-    const int n_raw = tile_count[(size_t)t * CNT_STRIDE];
+    const int lane = threadIdx.x;
+    // (counters pair up inside a frame: the frame's words first, then the tile of the frame)
+    const int f = blockIdx.x / tiles_per_frame, t = blockIdx.x - f * tiles_per_frame;
+    tile_count += (size_t)f * tiles_per_frame * CNT_STRIDE;
+    tile_len += (size_t)f * tiles_per_frame;
+    seg += (size_t)f * tiles_per_frame * C;
+    const int n_raw = tile_count[CNT_AT(t)];
     const int n = min(n_raw, C);
     int *ids = seg + (size_t)t * C;
     if (n > 1) {
@@ -152,7 +158,8 @@ int finalize_lists(gi2d_workspace *ws, hipStream_t st)
     const int T = ws_tiles(ws);
     if (T > 0) {
         finalize_tiles_kernel<<<T, WAVE, 0, st>>>(ws->d_count, ws->d_len, ws->d_seg, ws->seg_cap,
-                                                  ws->d_status, ws->generation);
+                                                  ws->d_status, ws->generation,
+                                                  ws_tiles_per_frame(ws));
         int rc = launch_status();
         if (rc != GI2D_OK) return rc;
     }

@@ -261,12 +261,21 @@ __global__ __launch_bounds__(AGG_THREADS) void project_agg_fwd_kernel(
         cnt[2] = c.z;
         cnt[3] = c.w;
     }
+    // (the counters of tiles 2j and 2j+1 are neighbouring words: one 64-bit atomic reserves for
+    // both; a pair this workgroup never touched keeps zeros nobody reads)
+    static_assert(PER_LANE % 2 == 0, "tiles are reserved in pairs");
 #pragma unroll
-    for (int k = 0; k < PER_LANE; ++k) {
-        base[k] = 0;
-        // (a tile this workgroup never touched keeps a zero nobody reads)
-        if (cnt[k] > 0)
-            base[k] = atomicAdd(&a.lists.tile_count[(size_t)(t4 + k) * CNT_STRIDE], cnt[k]);
+    for (int k = 0; k < PER_LANE; k += 2) {
+        base[k] = base[k + 1] = 0;
+        if ((cnt[k] | cnt[k + 1]) != 0) {
+            unsigned long long *pair =
+                reinterpret_cast<unsigned long long *>(a.lists.tile_count + CNT_AT(t4 + k));
+            const unsigned long long old = atomicAdd(
+                pair, (unsigned long long)(unsigned)cnt[k] |
+                          ((unsigned long long)(unsigned)cnt[k + 1] << 32));
+            base[k] = (int)(unsigned)old;
+            base[k + 1] = (int)(unsigned)(old >> 32);
+        }
     }
     // exclusive prefix of the counts over the tiles: where each tile's run starts in the stage
     const int lane = tid & 63, wave = tid >> 6;
@@ -435,7 +444,8 @@ __global__ __launch_bounds__(AGG_THREADS) void fill_bands_kernel(
     __syncthreads();
     // (the counters were zero: the rasteriser returns them to zero after reading them)
     for (int t = tid; t < band_tiles; t += AGG_THREADS)
-        if (cnt[t] > 0) tile_count[(t0 + t) * CNT_STRIDE] = cnt[t];
+        if (cnt[t] > 0)
+            tile_count[(size_t)f * tiles_per_frame * CNT_STRIDE + CNT_AT(r0 * tiles_x + t)] = cnt[t];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -662,7 +672,7 @@ __global__ __launch_bounds__(CELL_THREADS) void fill_cells_kernel(
         const int ly = tid / w;
         t = (ty0 - cg.row0 + ly) * tiles_x + tx0 + (tid - ly * w);
         // (the counters were zero: the rasteriser returns them to zero after reading them)
-        if (cnt > 0) tile_count[(size_t)t * CNT_STRIDE] = cnt;
+        if (cnt > 0) tile_count[CNT_AT(t)] = cnt;
     }
     tile_of[tid] = t;
     int total;

@@ -98,7 +98,7 @@ __device__ __forceinline__ int fwd_tile(
     // the first batch's id is loaded before the list length is known (a segment always has C
     // words): one round trip to memory instead of two
     int gid_first = tid < C ? lst[tid] : 0;
-    const int n_raw = FINALIZE ? tile_count[(size_t)t * CNT_STRIDE] : tile_len[t];
+    const int n_raw = FINALIZE ? tile_count[CNT_AT(t)] : tile_len[t];
     const int n_all = min(n_raw, C);
     float xacc[NX ? NX : 1];
 #pragma unroll

@@ -76,7 +76,7 @@ __device__ __forceinline__ void emit_tiles(int g, const TileBox &box, int row0, 
 #pragma unroll
             for (int u = 0; u < EMIT_FLIGHT; ++u) {
                 pos[u] = C;
-                if (t[u] >= 0) pos[u] = atomicAdd(&tile_count[(size_t)t[u] * CNT_STRIDE], 1);
+                if (t[u] >= 0) pos[u] = atomicAdd(&tile_count[CNT_AT(t[u])], 1);
             }
 #pragma unroll
             for (int u = 0; u < EMIT_FLIGHT; ++u)
@@ -99,7 +99,7 @@ __device__ __forceinline__ void emit_tiles(int g, const TileBox &box, int row0, 
         for (int u = 0; u < EMIT_FLIGHT; ++u) {
             pos[u] = 0;
             if (t[u] >= 0 && leader[u] == lane)
-                pos[u] = atomicAdd(&tile_count[(size_t)t[u] * CNT_STRIDE], gsize[u]);
+                pos[u] = atomicAdd(&tile_count[CNT_AT(t[u])], gsize[u]);
         }
 #pragma unroll
         for (int u = 0; u < EMIT_FLIGHT; ++u) {
@@ -198,7 +198,7 @@ __device__ __forceinline__ void finalize_tile_words(int t, int n_raw, int C, int
                                                     long long generation)
 {
     tile_len[t] = n_raw;
-    tile_count[(size_t)t * CNT_STRIDE] = 0;
+    tile_count[CNT_AT(t)] = 0;
     // Raising the published maximum is rare: only lists past half the capacity try, and only
     // those above the value already there reach the atomic (thousands of tiles hammering one
     // word would otherwise serialise at the memory side).
