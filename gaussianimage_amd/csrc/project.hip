@@ -1032,8 +1032,10 @@ int project_impl(int kind, bool raw, const float *means, const float *cov_a, con
     } else if (agg) {
         // workgroups per frame: enough to spread over the chip, few enough to share counters
         // (measured at 8 x 30 000 Gaussians on 768x512: 8 / 16 / 30 workgroups per frame give
-        // 21.3 / 19.9 / 20.5 us against 35 us for the direct kernel)
-        int per_frame = max(1, min(cdiv(N, AGG_THREADS), 128 / frames));
+        // 21.3 / 19.9 / 20.5 us against 35 us for the direct kernel; at 24 x 30 000 with the
+        // counters reserved in pairs, 128 / 144 / 168 / 192 / 216 workgroups in all give
+        // 28.6 / 26.9 / 26.2 / 27.5 / 32.5 us)
+        int per_frame = max(1, min(cdiv(N, AGG_THREADS), 168 / frames));
         per_frame = max(per_frame, cdiv(N, AGG_THREADS * AGG_ROUNDS));
         const int chunk = cdiv(N, per_frame);
         const dim3 agrid(cdiv(N, chunk), frames);
