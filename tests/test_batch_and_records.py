@@ -203,7 +203,11 @@ def test_records_change_no_bit_of_a_fit_or_a_decode(kind):
                                              ("cholesky", 1, 40000, 1000, 1500, 1.0),
                                              ("rs", 1, 5000, 300, 200, 20.0),
                                              ("cholesky", 1, 2500, 2100, 40, 2.0),
-                                             ("cholesky", 1, 2048, 512, 512, 60.0)])
+                                             ("cholesky", 1, 2048, 512, 512, 60.0),
+                                             # (odd tile counts per frame: the counters pair up
+                                             # inside a frame)
+                                             ("cholesky", 5, 6000, 200, 176, 1.0),
+                                             ("rs", 3, 2500, 72, 112, 2.0)])
 def test_list_filling_forms_give_the_same_lists(kind, F, N, H, W, fp):
     """The projection that counts its tiles in LDS (one counter atomic per tile a workgroup
     touches) and the one that fills the lists by bands of tile rows (no counter atomics) against
