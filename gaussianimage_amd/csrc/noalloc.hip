@@ -5,7 +5,7 @@
 
 #include "host.h"
 
-// Layout of the array (bytes): per-tile counters (one per 128-byte line), list lengths, status
+// Layout of the array (bytes): per-tile counters (128 bytes per tile, CNT_AT), list lengths, status
 // words, then the id segments of all tiles.
 #define NA_COUNT_BYTES ((size_t)GI2D_NOALLOC_MAX_TILES * CNT_STRIDE * sizeof(int))
 #define NA_LEN_BYTES ((size_t)GI2D_NOALLOC_MAX_TILES * sizeof(int))
