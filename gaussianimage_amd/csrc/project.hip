@@ -581,8 +581,20 @@ __global__ __launch_bounds__(CELL_THREADS) void project_cells_fwd_kernel(
     __syncthreads();
     // lane = cell: reserve (in flight until the copy-out), and find each cell's run in the stage
     const int cnt = chist[tid];  // (zero past the frame's cells)
+    // (the counters of cells 2j and 2j+1 are neighbouring words, CNT_AT: the even lane reserves
+    // for both with one 64-bit atomic and hands the odd lane its half)
     int base = 0;
-    if (cnt > 0) base = atomicAdd(&cg.count[(size_t)tid * CNT_STRIDE], cnt);
+    {
+        const int cnt_other = __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, false);  // lane ^ 1
+        unsigned long long old = 0ull;
+        if ((tid & 1) == 0 && (cnt | cnt_other) != 0)
+            old = atomicAdd(reinterpret_cast<unsigned long long *>(cg.count + CNT_AT(tid)),
+                            (unsigned long long)(unsigned)cnt |
+                                ((unsigned long long)(unsigned)cnt_other << 32));
+        const int lo = (int)(unsigned)old, hi = (int)(unsigned)(old >> 32);
+        const int hi_from_even = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+        base = (tid & 1) ? hi_from_even : lo;
+    }
     int total;
     const int off = block_exclusive_scan_1024(cnt, wave_sum, total);
     if (total <= CELL_STAGE1) {
@@ -635,10 +647,10 @@ __global__ __launch_bounds__(CELL_THREADS) void fill_cells_kernel(
         cg.count += (size_t)f * cg.cells * CNT_STRIDE;
         cg.bucket += (size_t)f * cg.cells * cg.cap;
     }
-    const int n = min(cg.count[(size_t)c * CNT_STRIDE], cg.cap);
+    const int n = min(cg.count[CNT_AT(c)], cg.cap);
     hist[tid] = 0;
     __syncthreads();  // (every lane has read the counter)
-    if (tid == 0) cg.count[(size_t)c * CNT_STRIDE] = 0;  // for the next frame
+    if (tid == 0) cg.count[CNT_AT(c)] = 0;  // for the next frame
     const int side = 1 << cg.log2_side;
     const int tx0 = (c % cg.cells_x) << cg.log2_side, tx1 = min(tiles_x, tx0 + side);
     const int ty0 = cg.row0 + ((c / cg.cells_x) << cg.log2_side), ty1 = min(cg.row1, ty0 + side);
